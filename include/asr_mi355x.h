@@ -1,0 +1,203 @@
+/* libasr_mi355x.so - C ABI of the MI355X-native (gfx950) ASR training hot path.
+ *
+ * Drop-in scope: the arithmetic that cosmoquester/speech-recognition's `run.train` delegates to
+ * TensorFlow ops.  The reference has no FFI of its own (it is pure
+ * Python on TF), so every entry point cites the reference call site (file:line under
+ * /root/reference/speech_recognition) whose TF op it replaces.
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: device pointers are raw pointers, `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream).
+ *   - the caller allocates and owns every buffer (including workspaces); the library keeps no
+ *     pointer after a call returns and holds no mutable global state besides the last-error string.
+ *   - every call is asynchronous on `stream`, safe to capture into a hipGraph (no allocation, no
+ *     synchronisation, no host read-back inside).
+ *   - return value: ASR_OK (0) or a negative asr_status; asr_last_error() describes the failure.
+ *   - all matrices are row-major f32 unless stated; masks are uint8 (0/1); token ids int32.
+ *   - randomness (dropout, SpecAugment) comes from the stateless hash RNG documented in
+ *     oracle/rng.py: r(seed, stream, idx); `seed` is read from DEVICE memory (so a captured graph
+ *     sees a fresh seed every replay), `stream_id` names the draw site.
+ */
+#ifndef ASR_MI355X_H
+#define ASR_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum asr_status {
+  ASR_OK = 0,
+  ASR_ERR_ARG = -1,         /* null pointer / inconsistent flags        */
+  ASR_ERR_SHAPE = -2,       /* shape the kernels do not support         */
+  ASR_ERR_UNSUPPORTED = -3, /* e.g. unknown rnn_type (las.py:17)        */
+  ASR_ERR_HIP = -4          /* HIP runtime / launch failure             */
+} asr_status;
+
+const char* asr_last_error(void);
+int asr_version(void);
+/* sizeof(struct <name>) as compiled into the library (-1 = unknown): lets a binding verify its mirror */
+long asr_struct_size(const char* name);
+
+/* ------------------------------------------------------------------------------------------
+ * Front end: log-mel + SpecAugment + delta/delta-delta + zero padding, one fused kernel.
+ * Replaces data.py:169-187 (tf.signal.stft, tf.abs, tf.square, linear_to_mel_weight_matrix,
+ * tf.matmul, tf.math.log), data.py:282-301 (SpecAugment frequency/time masks),
+ * data.py:319-324 (delta_accelerate) and the zero padding of run/train.py:189-197.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct asr_logmel_cfg {
+  int sample_rate, frame_length, frame_step, fft_length, num_mel_bins;
+  float lower_edge_hertz, upper_edge_hertz, epsilon;
+  int use_delta;                       /* 1: output [..., 3] (x, delta, delta-delta); 0: [..., 1] */
+  int sa_enable, sa_F, sa_mF, sa_T, sa_mT; /* SpecAugment; time warp (W) is not supported     */
+  float sa_p;
+} asr_logmel_cfg;
+
+/* sizes (in elements) of the three constant tables the kernel reads */
+int asr_logmel_table_sizes(const asr_logmel_cfg* cfg, long* n_twiddle_f32, long* n_melw_f32, long* n_melrange_i32);
+/* fills HOST buffers (computed in double, rounded to f32); the caller uploads them once */
+int asr_logmel_build_tables(const asr_logmel_cfg* cfg, float* twiddle, float* melw, int32_t* melrange);
+/* audio [B, n_max] f32 (device), n_samples [B] int32 (device) -> out [B, T_out, mel, C] f32.
+ * Frames t >= frames(n_samples[b]) are written as exact 0.0.  seed may be NULL when !sa_enable. */
+int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio, const int32_t* n_samples, int B, int n_max,
+                        const float* twiddle, const float* melw, const int32_t* melrange, const uint32_t* seed,
+                        float* out, int T_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense contraction (tf.matmul / Dense / the batched halves of LSTM, attention and vocab
+ * projections: las.py:43-59,169,193,196-202,264; deepspeech2.py:177; and every weight/input
+ * gradient of those).  C[z] (+)= alpha * op(A[z]) op(B[z]) (+ bias), exact f32 on the MFMA.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct asr_gemm_desc {
+  int trans_a, trans_b;        /* 0: A is [M,K] / B is [K,N];  1: A is [K,M] / B is [N,K]          */
+  int M, N, K;
+  int batch;                   /* z extent (>= 1)                                                   */
+  long lda, ldb, ldc;          /* row strides of the stored matrices, in elements                   */
+  long stride_a, stride_b, stride_c, stride_a_scale; /* per-z strides; stride_c == 0 with batch > 1 = split-K (atomic) */
+  float alpha;
+  int accumulate;              /* 0: C = ..., 1: C += ..., 2: atomicAdd                             */
+  int relu;
+  const float* bias;           /* [N] or NULL                                                       */
+  const float* a_scale;        /* optional multiplier on stored A: a_scale[(row / a_rpg) * cols + col] */
+  int a_rpg;
+  const float* c_scale;        /* optional multiplier on C: c_scale[(row / c_rpg) * N + col]        */
+  int c_rpg;
+} asr_gemm_desc;
+int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Recurrent layers: Keras LSTM / GRU(reset_after=True) / SimpleRNN with K.rnn mask semantics
+ * (las.py:10-17 get_rnn_cls, las.py:62-126 BiRNN, las.py:259-262 + 285-288 decoder cells,
+ * deepspeech2.py:109-119).  rnn_type: 0 = "lstm", 1 = "gru", 2 = "rnn".
+ * One kernel launch per time step; a BiRNN's two directions share each launch.
+ * ------------------------------------------------------------------------------------------ */
+#define ASR_RNN_LSTM 0
+#define ASR_RNN_GRU 1
+#define ASR_RNN_RNN 2
+#define ASR_RNN_MAXSEG 3
+
+typedef struct asr_rnn_geom {
+  int Q;                       /* unit groups of 4: ceil(H / 4)                                   */
+  int KSt;                     /* packed K steps: sum over segments of ceil(K_i / 4)              */
+  int NT;                      /* slab column tiles: ceil(4 KSt / 16)                             */
+  int ks0[ASR_RNN_MAXSEG];     /* first K step of each segment; its first packed column = 4 ks0   */
+  long wp_floats, wpb_floats;  /* sizes of the two packed weight images                           */
+  int slab_ld;                 /* slab row length = 16 NT                                         */
+} asr_rnn_geom;
+int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr_rnn_geom* g);
+
+/* Pack the weights multiplying the concatenated cell input [seg0 | seg1 | ...] (each W[i] is
+ * [K_i, G*H] Keras layout, row stride ldw[i]; is_rec marks the recurrent segment) into MFMA
+ * fragment order.  Must be re-run whenever the weights change (once per optimizer step). */
+int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const long* ldw, const int* K, const int* is_rec,
+                 float* Wp, float* Wpb, void* stream);
+
+/* One cell step for one direction; row b of every matrix is at ptr + b * ld. */
+typedef struct asr_rnn_step_fwd {
+  int nseg, KSt;
+  const float* Wp;
+  const float* seg_x[ASR_RNN_MAXSEG];       /* inputs multiplying the packed weights              */
+  long seg_ld[ASR_RNN_MAXSEG];
+  int seg_K[ASR_RNN_MAXSEG], seg_ks0[ASR_RNN_MAXSEG];
+  float seg_drop_rate[ASR_RNN_MAXSEG];      /* > 0: inverted dropout on that input, element index  */
+  uint32_t seg_drop_stream[ASR_RNN_MAXSEG]; /*      = b * seg_drop_ld + seg_drop_off + k           */
+  long seg_drop_ld[ASR_RNN_MAXSEG];
+  int seg_drop_off[ASR_RNN_MAXSEG];
+  const float* pre; long pre_ld;            /* pre-computed input projection [B, G*H] or NULL     */
+  const float* bias;                        /* [G*H] added to pre (NULL if pre already has it)     */
+  const float* bias_rec;                    /* GRU recurrent bias [3H] or NULL                     */
+  const float* h_prev; long h_prev_ld;
+  const float* c_prev; long c_prev_ld;      /* LSTM                                                */
+  const float* y_prev; long y_prev_ld;      /* previously emitted output, NULL = zeros             */
+  const uint8_t* mask; long mask_ld;        /* mask[b * mask_ld], NULL = all valid                 */
+  float* h_out; long h_out_ld;
+  float* c_out; long c_out_ld;
+  float* y_out; long y_out_ld;
+  float* saved; long saved_ld;              /* activations for backward [B, NS*H], NS = 4,4,1      */
+} asr_rnn_step_fwd;
+int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fwd* steps, const uint32_t* seed,
+                     void* stream);
+
+typedef struct asr_rnn_step_bwd {
+  int KSt, NT;
+  const float* Wpb;
+  /* d loss / d (state h leaving the cell) = sum_q slabA[q][b][colA + j] + addA[b][j]               */
+  const float* slabA; int QA; long slabA_qstride, slabA_ld; int colA;
+  const float* addA; long addA_ld;
+  /* d loss / d (emitted output y)         = sum_q slabB[q][b][colB + j] + addB[b][j]               */
+  const float* slabB; int QB; long slabB_qstride, slabB_ld; int colB;
+  const float* addB; long addB_ld;
+  float* dc; long dc_ld;                    /* LSTM cell-state gradient, updated in place          */
+  float* dy_carry; long dy_carry_ld;        /* pending output gradient across masked steps or NULL */
+  const uint8_t* mask; long mask_ld;
+  const float* saved; long saved_ld;
+  const float* h_prev; long h_prev_ld;
+  const float* c_prev; long c_prev_ld;
+  const float* c_out; long c_out_ld;
+  float* dslots; long dslots_ld;            /* out: gradient wrt the gate sums [B, NS*H] (may alias saved) */
+  float* slab_out; long slab_out_qstride, slab_out_ld; /* out: [Q][Bpad][16 NT] partial input gradients or NULL */
+  int hcol;                                 /* first packed column of the recurrent segment        */
+} asr_rnn_step_bwd;
+int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, void* stream);
+
+/* out[b][c] (+)= sum_q slab[q][b][col0 + c] (+ add[b][c]) */
+int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
+                    long add_ld, float* out, long out_ld, int accumulate, void* stream);
+
+/* A whole (Bi)RNN layer over time.  Tensors are batch-major: pre [B,T,G*H] (input projection incl.
+ * bias), hseq/cseq [B,T,H] (states after each step, time order), y [B,T,y_ld] with direction d
+ * writing columns [y_col[d], y_col[d]+H) (so forward|backward concatenation and the re-reversal
+ * of las.py:125 are free), saved [B,T,NS*H] (LSTM/RNN: may alias pre), mask [B,T] uint8 or NULL. */
+typedef struct asr_rnn_seq {
+  int rnn_type, B, T, H, ndir;
+  int reverse[2];                           /* 1: go_backwards                                      */
+  const float* pre[2];
+  const float* Wp[2]; const float* Wpb[2];
+  const float* bias_rec[2];                 /* GRU                                                   */
+  const float* h0[2]; long h0_ld[2];        /* initial states (NULL = zeros)                         */
+  const float* c0[2]; long c0_ld[2];
+  const float* rec_mult[2];                 /* reserved (recurrent dropout), must be NULL            */
+  const uint8_t* mask;
+  float* hseq[2]; float* cseq[2];
+  float* y; long y_ld; int y_col[2];
+  float* saved[2];
+} asr_rnn_seq;
+int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream);
+
+typedef struct asr_rnn_seq_grad {
+  const float* dy; long dy_ld;              /* gradient wrt y, same layout as y                      */
+  const float* dh_last[2]; long dh_last_ld[2]; /* gradient wrt the final h state or NULL            */
+  float* dc[2];                             /* [B,H]: in = gradient wrt final c, out = wrt initial c */
+  float* dy_carry[2];                       /* [B,H] scratch, zeroed by the caller (masked runs)     */
+  float* slab[2];                           /* scratch: 2 * Q * Bpad * slab_ld floats per direction  */
+  float* dh0[2]; long dh0_ld[2];            /* out: gradient wrt initial h or NULL                   */
+} asr_rnn_seq_grad;
+/* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs. */
+int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_MI355X_H */

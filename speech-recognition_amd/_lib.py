@@ -1,0 +1,140 @@
+"""ctypes binding of libasr_mi355x.so (C ABI declared in include/asr_mi355x.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing or a symbol cannot be resolved, importing the ops raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasr_mi355x.so")
+
+RNN_TYPES = {"lstm": 0, "gru": 1, "rnn": 2}
+RNN_MAXSEG = 3
+
+c_f32p = C.c_void_p  # device pointers travel as raw addresses
+c_long = C.c_long
+
+
+class LogmelCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("frame_length", C.c_int), ("frame_step", C.c_int), ("fft_length", C.c_int),
+                ("num_mel_bins", C.c_int), ("lower_edge_hertz", C.c_float), ("upper_edge_hertz", C.c_float),
+                ("epsilon", C.c_float), ("use_delta", C.c_int), ("sa_enable", C.c_int), ("sa_F", C.c_int),
+                ("sa_mF", C.c_int), ("sa_T", C.c_int), ("sa_mT", C.c_int), ("sa_p", C.c_float)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("trans_a", C.c_int), ("trans_b", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("batch", C.c_int), ("lda", c_long), ("ldb", c_long), ("ldc", c_long), ("stride_a", c_long),
+                ("stride_b", c_long), ("stride_c", c_long), ("stride_a_scale", c_long), ("alpha", C.c_float),
+                ("accumulate", C.c_int), ("relu", C.c_int), ("bias", c_f32p), ("a_scale", c_f32p), ("a_rpg", C.c_int),
+                ("c_scale", c_f32p), ("c_rpg", C.c_int)]
+
+
+class RnnGeom(C.Structure):
+    _fields_ = [("Q", C.c_int), ("KSt", C.c_int), ("NT", C.c_int), ("ks0", C.c_int * RNN_MAXSEG),
+                ("wp_floats", c_long), ("wpb_floats", c_long), ("slab_ld", C.c_int)]
+
+
+class RnnStepFwd(C.Structure):
+    _fields_ = [("nseg", C.c_int), ("KSt", C.c_int), ("Wp", c_f32p),
+                ("seg_x", c_f32p * RNN_MAXSEG), ("seg_ld", c_long * RNN_MAXSEG),
+                ("seg_K", C.c_int * RNN_MAXSEG), ("seg_ks0", C.c_int * RNN_MAXSEG),
+                ("seg_drop_rate", C.c_float * RNN_MAXSEG), ("seg_drop_stream", C.c_uint32 * RNN_MAXSEG),
+                ("seg_drop_ld", c_long * RNN_MAXSEG), ("seg_drop_off", C.c_int * RNN_MAXSEG),
+                ("pre", c_f32p), ("pre_ld", c_long), ("bias", c_f32p), ("bias_rec", c_f32p),
+                ("h_prev", c_f32p), ("h_prev_ld", c_long), ("c_prev", c_f32p), ("c_prev_ld", c_long),
+                ("y_prev", c_f32p), ("y_prev_ld", c_long), ("mask", c_f32p), ("mask_ld", c_long),
+                ("h_out", c_f32p), ("h_out_ld", c_long), ("c_out", c_f32p), ("c_out_ld", c_long),
+                ("y_out", c_f32p), ("y_out_ld", c_long), ("saved", c_f32p), ("saved_ld", c_long)]
+
+
+class RnnStepBwd(C.Structure):
+    _fields_ = [("KSt", C.c_int), ("NT", C.c_int), ("Wpb", c_f32p),
+                ("slabA", c_f32p), ("QA", C.c_int), ("slabA_qstride", c_long), ("slabA_ld", c_long), ("colA", C.c_int),
+                ("addA", c_f32p), ("addA_ld", c_long),
+                ("slabB", c_f32p), ("QB", C.c_int), ("slabB_qstride", c_long), ("slabB_ld", c_long), ("colB", C.c_int),
+                ("addB", c_f32p), ("addB_ld", c_long),
+                ("dc", c_f32p), ("dc_ld", c_long), ("dy_carry", c_f32p), ("dy_carry_ld", c_long),
+                ("mask", c_f32p), ("mask_ld", c_long), ("saved", c_f32p), ("saved_ld", c_long),
+                ("h_prev", c_f32p), ("h_prev_ld", c_long), ("c_prev", c_f32p), ("c_prev_ld", c_long),
+                ("c_out", c_f32p), ("c_out_ld", c_long), ("dslots", c_f32p), ("dslots_ld", c_long),
+                ("slab_out", c_f32p), ("slab_out_qstride", c_long), ("slab_out_ld", c_long), ("hcol", C.c_int)]
+
+
+class RnnSeq(C.Structure):
+    _fields_ = [("rnn_type", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("ndir", C.c_int),
+                ("reverse", C.c_int * 2), ("pre", c_f32p * 2), ("Wp", c_f32p * 2), ("Wpb", c_f32p * 2),
+                ("bias_rec", c_f32p * 2), ("h0", c_f32p * 2), ("h0_ld", c_long * 2), ("c0", c_f32p * 2),
+                ("c0_ld", c_long * 2), ("rec_mult", c_f32p * 2), ("mask", c_f32p),
+                ("hseq", c_f32p * 2), ("cseq", c_f32p * 2), ("y", c_f32p), ("y_ld", c_long), ("y_col", C.c_int * 2),
+                ("saved", c_f32p * 2)]
+
+
+class RnnSeqGrad(C.Structure):
+    _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
+                ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("slab", c_f32p * 2), ("dh0", c_f32p * 2),
+                ("dh0_ld", c_long * 2)]
+
+
+STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom,
+           "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
+           "asr_rnn_seq_grad": RnnSeqGrad}
+
+# symbol -> (restype, argtypes); every function declared in include/asr_mi355x.h
+_P = C.c_void_p
+SIGNATURES = {
+    "asr_last_error": (C.c_char_p, []),
+    "asr_version": (C.c_int, []),
+    "asr_struct_size": (c_long, [C.c_char_p]),
+    "asr_logmel_table_sizes": (C.c_int, [C.POINTER(LogmelCfg), C.POINTER(c_long), C.POINTER(c_long), C.POINTER(c_long)]),
+    "asr_logmel_build_tables": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, _P]),
+    "asr_logmel_features": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "asr_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
+    "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
+    "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
+                               C.POINTER(C.c_int), _P, _P, _P]),
+    "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
+    "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P]),
+    "asr_slab_reduce": (C.c_int, [_P, C.c_int, c_long, c_long, C.c_int, C.c_int, C.c_int, _P, c_long, _P, c_long,
+                                  C.c_int, _P]),
+    "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
+    "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),
+}
+
+_lib = None
+
+
+class AsrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once). Fails loudly: no fallback path exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C speech-recognition_amd/csrc`). speech_recognition_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    for cname, cls in STRUCTS.items():
+        n = lib.asr_struct_size(cname.encode())
+        if n != C.sizeof(cls):
+            raise ImportError(f"ABI mismatch: sizeof({cname}) is {n} in the library, {C.sizeof(cls)} in the binding")
+    _lib = lib
+    return lib
+
+
+_EXC = {-1: ValueError, -2: ValueError, -3: ValueError, -4: AsrError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().asr_last_error().decode()
+        raise _EXC.get(rc, AsrError)(msg)

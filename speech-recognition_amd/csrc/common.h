@@ -1,0 +1,95 @@
+// Shared device/host helpers for libasr_mi355x (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/asr_mi355x.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ASR_WAVE 64
+
+// ---------------------------------------------------------------- host-side status plumbing
+void asr_set_error(const char* fmt, ...);
+#define ASR_CHECK(cond, code, ...)          \
+  do {                                      \
+    if (!(cond)) {                          \
+      asr_set_error(__VA_ARGS__);           \
+      return (code);                        \
+    }                                       \
+  } while (0)
+#define ASR_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      asr_set_error("%s: HIP launch error: %s", __func__, hipGetErrorString(e__)); \
+      return ASR_ERR_HIP;                                               \
+    }                                                                   \
+  } while (0)
+
+static inline int asr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- stateless RNG (spec: oracle/rng.py)
+__host__ __device__ __forceinline__ uint32_t asr_fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+struct AsrRngKey { uint32_t k1, k2; };
+__host__ __device__ __forceinline__ AsrRngKey asr_rng_key(uint32_t seed, uint32_t stream) {
+  AsrRngKey k;
+  k.k1 = asr_fmix32(seed ^ (stream * 0x9E3779B1u + 0x7F4A7C15u));
+  k.k2 = asr_fmix32(k.k1 + 0x6A09E667u + stream);
+  return k;
+}
+__host__ __device__ __forceinline__ uint32_t asr_rng_u32(AsrRngKey k, uint32_t idx) {
+  return asr_fmix32(((idx ^ k.k1) * 0x9E3779B1u) + k.k2);
+}
+__host__ __device__ __forceinline__ uint32_t asr_drop_threshold(float rate) {
+  return rate > 0.f ? (uint32_t)(long long)((double)rate * 4294967296.0) : 0u;
+}
+// inverted-dropout multiplier for element idx
+__device__ __forceinline__ float asr_drop_mult(AsrRngKey k, uint32_t idx, uint32_t thresh, float scale) {
+  return asr_rng_u32(k, idx) >= thresh ? scale : 0.f;
+}
+__host__ __device__ __forceinline__ int asr_uniform_int(AsrRngKey k, uint32_t idx, int n) {
+  if (n <= 0) return 0;
+  return (int)(((uint64_t)asr_rng_u32(k, idx) * (uint64_t)(uint32_t)n) >> 32);
+}
+
+// ---------------------------------------------------------------- wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block reductions for <= 16 waves; `red` must hold >= 16 floats of LDS; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+
+// accurate (ocml) transcendental forms: the gate math is latency-, not throughput-bound
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }

@@ -1,0 +1,32 @@
+// Status plumbing of libasr_mi355x: last-error string and version.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/asr_mi355x.h"
+
+static thread_local char g_err[512] = "";
+
+void asr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* asr_last_error(void) { return g_err; }
+extern "C" int asr_version(void) { return 100; }
+
+// sizeof of every ABI struct, so that a binding (ctypes, cgo, JNI...) can verify its mirror
+extern "C" long asr_struct_size(const char* name) {
+#define SZ(T) if (!strcmp(name, #T)) return (long)sizeof(T)
+  SZ(asr_logmel_cfg);
+  SZ(asr_gemm_desc);
+  SZ(asr_rnn_geom);
+  SZ(asr_rnn_step_fwd);
+  SZ(asr_rnn_step_bwd);
+  SZ(asr_rnn_seq);
+  SZ(asr_rnn_seq_grad);
+#undef SZ
+  return -1;
+}

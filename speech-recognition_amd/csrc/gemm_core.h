@@ -1,0 +1,181 @@
+// f32 MFMA GEMM core for gfx950: C[M,N] (+)= alpha * op(A)[M,K] * op(B)[K,N] (+ bias), exact f32
+// (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain).  The tile loaders are policies so that the
+// same main loop serves plain matrices, im2col views (conv fwd / bwd-filter) and the gathered
+// views of conv bwd-data.
+//
+// Tiling: 256 threads = 4 waves arranged WAVES_M x WAVES_N; each wave owns MI x NI tiles of 32x32;
+// BK = 32.  A and B tiles are staged global -> registers -> LDS with the next tile's global
+// loads in flight during the MFMAs of the current one.
+//
+// LDS images (so that every MFMA operand read is a conflict-free ds_read_b32):
+//   operand whose K index is contiguous in memory  -> [mn][k] rows of BK+1 floats (odd stride)
+//   operand whose M/N index is contiguous          -> [k][mn] rows of BM/BN floats
+#pragma once
+#include "common.h"
+
+#define GEMM_BK 32
+
+// ---- loader policies: fetch4(r, c, v) reads stored[r][c..c+3] with zero fill outside [R, Cc)
+struct PlainLoader {
+  const float* p;
+  long ld;
+  int R, Cc;       // stored rows / cols
+  int vec_ok;      // base and ld 16-byte aligned
+  const float* scale;  // optional group scale [R / rpg][Cc]
+  int rpg;
+  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
+    if (r < R && c + 3 < Cc && vec_ok) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (long)r * ld + c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (r < R && c + i < Cc) ? p[(long)r * ld + c + i] : 0.f;
+    }
+    if (scale != nullptr && r < R) {
+      const float* s = scale + (long)(r / rpg) * Cc + c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c + i < Cc) v[i] *= s[i];
+    }
+  }
+};
+
+struct GemmEpilogue {
+  float* C;
+  long ldc;
+  int M, N;
+  float alpha;
+  const float* bias;     // [N] or null
+  const float* c_scale;  // optional [M / c_rpg][N]
+  int c_rpg;
+  int mode;              // 0 store, 1 accumulate (+=), 2 atomic add
+  int relu;
+  __device__ __forceinline__ void put(int r, int c, float v) const {
+    if (r >= M || c >= N) return;
+    v *= alpha;
+    if (bias != nullptr) v += bias[c];
+    if (c_scale != nullptr) v *= c_scale[(long)(r / c_rpg) * N + c];
+    if (relu) v = fmaxf(v, 0.f);
+    float* dst = C + (long)r * ldc + c;
+    if (mode == 0) *dst = v;
+    else if (mode == 1) *dst += v;
+    else atomicAdd(dst, v);
+  }
+};
+
+// TA: 0 -> A stored [M][K] (k contiguous); 1 -> A stored [K][M] (m contiguous). Same for TB with
+// 0 -> B stored [K][N] (n contiguous); 1 -> B stored [N][K] (k contiguous).
+template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
+struct GemmTile {
+  static constexpr int BK = GEMM_BK;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  static constexpr int MI = WM / 32, NI = WN / 32;
+  static constexpr int A_KC = (TA == 0);  // A has k contiguous
+  static constexpr int B_KC = (TB == 1);  // B has k contiguous
+  static constexpr int A_LD = A_KC ? (BK + 1) : BM;
+  static constexpr int B_LD = B_KC ? (BK + 1) : BN;
+  static constexpr int A_ELEMS = A_KC ? BM * (BK + 1) : BK * BM;
+  static constexpr int B_ELEMS = B_KC ? BN * (BK + 1) : BK * BN;
+  static constexpr int A_V4 = BM * BK / 4 / 256;  // float4 fetches per thread per tile
+  static constexpr int B_V4 = BN * BK / 4 / 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
+
+  template <class AL, class BL>
+  static __device__ __forceinline__ void run(const AL& al, const BL& bl, const GemmEpilogue& ep, int K,
+                                             int m0, int n0, float* As, float* Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    float ra[A_V4][4], rb[B_V4][4];
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto gload = [&](int k0) {
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i) {
+        const int f = tid + i * 256;
+        if (A_KC) { const int r = f / (BK / 4), q = f % (BK / 4); al.fetch4(m0 + r, k0 + 4 * q, ra[i]); }
+        else      { const int r = f / (BM / 4), q = f % (BM / 4); al.fetch4(k0 + r, m0 + 4 * q, ra[i]); }
+      }
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) {
+        const int f = tid + i * 256;
+        if (B_KC) { const int r = f / (BK / 4), q = f % (BK / 4); bl.fetch4(n0 + r, k0 + 4 * q, rb[i]); }
+        else      { const int r = f / (BN / 4), q = f % (BN / 4); bl.fetch4(k0 + r, n0 + 4 * q, rb[i]); }
+      }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i) {
+        const int f = tid + i * 256;
+        if (A_KC) {
+          const int r = f / (BK / 4), q = f % (BK / 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) As[r * A_LD + 4 * q + e] = ra[i][e];
+        } else {
+          const int r = f / (BM / 4), q = f % (BM / 4);
+          *reinterpret_cast<float4*>(&As[r * A_LD + 4 * q]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) {
+        const int f = tid + i * 256;
+        if (B_KC) {
+          const int r = f / (BK / 4), q = f % (BK / 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Bs[r * B_LD + 4 * q + e] = rb[i][e];
+        } else {
+          const int r = f / (BN / 4), q = f % (BN / 4);
+          *reinterpret_cast<float4*>(&Bs[r * B_LD + 4 * q]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+        }
+      }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      lstore();
+      __syncthreads();
+      if (kt + 1 < nk) gload((kt + 1) * BK);
+      const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const int k = kk + lh;
+        float a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = wm * WM + i * 32 + l31;
+          a[i] = A_KC ? As[m * A_LD + k] : As[k * A_LD + m];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = wn * WN + j * 32 + l31;
+          b[j] = B_KC ? Bs[n * B_LD + k] : Bs[k * B_LD + n];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int col = n0 + wn * WN + j * 32 + l31;
+          ep.put(row, col, acc[i][j][r]);
+        }
+  }
+};

@@ -1,0 +1,571 @@
+// Recurrent cells for gfx950: Keras LSTM / GRU(reset_after) / SimpleRNN with K.rnn mask semantics
+// (las.py:62-126 BiRNN, las.py:259-262,285-288 decoder cells, deepspeech2.py:109-119).
+//
+// One launch = one time step (both directions of a BiRNN ride in blockIdx.z).  A launch boundary
+// on MI355X costs about what a hand-rolled grid barrier does (MI355X_MICROARCH price list rows
+// "boundary" vs "barrier-xcd") and cannot deadlock; the whole step sequence is meant to be
+// captured in a hipGraph by the caller.
+//
+// Work split: workgroup (q, bt, dir) owns hidden units [4q, 4q+4) x batch rows [16bt, 16bt+16).
+// The per-step product  [16 x Ktot] x [Ktot x 16 gate columns]  runs on v_mfma_f32_16x16x4_f32 with
+// K split across the 4 waves and reduced through LDS; wave 0 then does the gate math.  Weights are
+// re-packed once per optimizer step into MFMA fragment order (asr_rnn_pack) so every B-operand
+// load is one coalesced 256-byte wave access of an L2-resident 16 KB slice.
+//
+// "slot" = one of the 16 packed gate columns: slot = 4*s + u, u = unit within the group,
+//   LSTM s = gate i,f,c~,o        GRU s = z, r, x-part of h~, recurrent part of h~        RNN s = 0 only.
+//
+// Backward step: gate gradients for the owned units, then the partial product
+// dA_partial[16 x Ktot] = dslots[16 x 16] x Wslice^T goes to a per-workgroup slab; whoever consumes
+// a gradient (the previous step's cell, or asr_slab_reduce) sums the slabs of all q.  No atomics,
+// bit-reproducible.
+#include "common.h"
+
+#define CELL_LSTM 0
+#define CELL_GRU 1
+#define CELL_RNN 2
+
+static __host__ __device__ inline int cell_ngates(int cell) { return cell == CELL_LSTM ? 4 : (cell == CELL_GRU ? 3 : 1); }
+static __host__ __device__ inline int cell_nsaved(int cell) { return cell == CELL_RNN ? 1 : 4; }
+
+// ------------------------------------------------------------------------------------------ pack
+struct PackArgs {
+  const float* W[ASR_RNN_MAXSEG];
+  long ldw[ASR_RNN_MAXSEG];
+  int K[ASR_RNN_MAXSEG];
+  int ks0[ASR_RNN_MAXSEG];
+  int is_rec[ASR_RNN_MAXSEG];
+  int nseg, KSt, NT, H, Q, cell;
+  float* Wp;   // [Q][KSt][64]      forward fragments:  lane -> (k = 4ks + lane>>4, slot = lane&15)
+  float* Wpb;  // [Q][NT][4][64]    backward fragments: lane -> (slot = 4s4 + lane>>4, kcol = 16nt + lane&15)
+};
+
+__device__ __forceinline__ float pack_value(const PackArgs& a, int q, int kcol, int slot) {
+  // kcol indexes the packed (segment-padded) K axis
+  const int ks = kcol >> 2;
+  int s = -1;
+  for (int i = 0; i < a.nseg; ++i)
+    if (ks >= a.ks0[i] && ks < a.ks0[i] + (a.K[i] + 3) / 4) s = i;
+  if (s < 0) return 0.f;
+  const int k = kcol - 4 * a.ks0[s];
+  const int g = slot >> 2, u = slot & 3, j = 4 * q + u;
+  if (k >= a.K[s] || j >= a.H) return 0.f;
+  const float* W = a.W[s];
+  const long ld = a.ldw[s];
+  if (a.cell == CELL_LSTM) return W[k * ld + (long)g * a.H + j];
+  if (a.cell == CELL_GRU) {
+    if (g < 2) return W[k * ld + (long)g * a.H + j];
+    if (g == 2) return a.is_rec[s] ? 0.f : W[k * ld + 2L * a.H + j];
+    return a.is_rec[s] ? W[k * ld + 2L * a.H + j] : 0.f;
+  }
+  return g == 0 ? W[k * ld + j] : 0.f;
+}
+
+__global__ void rnn_pack_kernel(PackArgs a) {
+  const long nf = (long)a.Q * a.KSt * 64, nb = (long)a.Q * a.NT * 4 * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int lane = (int)(i & 63);
+      const long r = i >> 6;
+      const int ks = (int)(r % a.KSt), q = (int)(r / a.KSt);
+      a.Wp[i] = pack_value(a, q, 4 * ks + (lane >> 4), lane & 15);
+    } else {
+      const long i2 = i - nf;
+      const int lane = (int)(i2 & 63);
+      long r = i2 >> 6;
+      const int s4 = (int)(r & 3); r >>= 2;
+      const int nt = (int)(r % a.NT), q = (int)(r / a.NT);
+      a.Wpb[i2] = pack_value(a, q, 16 * nt + (lane & 15), 4 * s4 + (lane >> 4));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward step
+struct FwdSeg {
+  const float* x; long ld; int K; int ks0;
+  int drop; uint32_t drop_stream; float drop_rate; long drop_ld; int drop_off;
+};
+struct FwdDir {
+  FwdSeg seg[ASR_RNN_MAXSEG];
+  int nseg, KSt;
+  const float* Wp;
+  const float* pre; long pre_ld;
+  const float* bias; const float* bias_rec;
+  const float* h_prev; long h_prev_ld;
+  const float* c_prev; long c_prev_ld;
+  const float* y_prev; long y_prev_ld;
+  const uint8_t* mask; long mask_ld;
+  float* h_out; long h_out_ld;
+  float* c_out; long c_out_ld;
+  float* y_out; long y_out_ld;
+  float* saved; long saved_ld;
+};
+struct FwdArgs { FwdDir d[2]; int B, H; const uint32_t* seed; };
+
+template <int CELL>
+__global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
+  __shared__ float part[4][16 * 17];
+  const FwdDir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int q = blockIdx.x, b0 = blockIdx.y * 16;
+  const int H = a.H, B = a.B;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* wp = d.Wp + (long)q * d.KSt * 64 + lane;
+  const int brow = b0 + li;
+  const uint32_t seedv = a.seed ? a.seed[0] : 0u;
+  for (int s = 0; s < d.nseg; ++s) {
+    const FwdSeg& sg = d.seg[s];
+    const int nks = (sg.K + 3) >> 2;
+    const AsrRngKey key = asr_rng_key(seedv, sg.drop_stream);
+    const uint32_t thr = asr_drop_threshold(sg.drop_rate);
+    const float dscale = 1.f / (1.f - sg.drop_rate);
+#pragma unroll 4
+    for (int ks = wave; ks < nks; ks += 4) {
+      const int k = 4 * ks + lq;
+      float av = (sg.x != nullptr && brow < B && k < sg.K) ? sg.x[(long)brow * sg.ld + k] : 0.f;
+      if (sg.drop) av *= asr_drop_mult(key, (uint32_t)((long)brow * sg.drop_ld + sg.drop_off + k), thr, dscale);
+      const float bv = wp[(long)(sg.ks0 + ks) * 64];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[wave][(lq * 4 + r) * 17 + li] = acc[r];
+  __syncthreads();
+  if (wave != 0) return;
+
+  const int bi = lane >> 2, u = lane & 3;
+  const int b = b0 + bi, j = 4 * q + u;
+  if (b >= B || j >= H) return;
+  float s[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    s[g] = part[0][bi * 17 + g * 4 + u] + part[1][bi * 17 + g * 4 + u] + part[2][bi * 17 + g * 4 + u] + part[3][bi * 17 + g * 4 + u];
+  const bool m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+  const float hp = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+  const float yp = d.y_prev ? d.y_prev[(long)b * d.y_prev_ld + j] : 0.f;
+  constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
+  float pre[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float v = d.pre ? d.pre[(long)b * d.pre_ld + (long)g * H + j] : 0.f;
+    if (d.bias) v += d.bias[(long)g * H + j];
+    pre[g] = v;
+  }
+  float hn, cn = 0.f;
+  if (CELL == CELL_LSTM) {
+    const float cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+    const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
+    const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
+    const float c2 = fg * cp + ig * gg;
+    hn = og * tanhf_(c2);
+    cn = m ? c2 : cp;
+    if (d.saved) {
+      float* sv = d.saved + (long)b * d.saved_ld + j;
+      sv[0] = ig; sv[H] = fg; sv[2L * H] = gg; sv[3L * H] = og;
+    }
+    if (d.c_out) d.c_out[(long)b * d.c_out_ld + j] = cn;
+  } else if (CELL == CELL_GRU) {
+    float br[3] = {0.f, 0.f, 0.f};
+    if (d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
+    const float z = sigmoidf_(pre[0] + s[0] + br[0]);
+    const float r = sigmoidf_(pre[1] + s[1] + br[1]);
+    const float arh = s[3] + br[2];
+    const float hh = tanhf_(pre[2] + s[2] + r * arh);
+    hn = z * hp + (1.f - z) * hh;
+    if (d.saved) {
+      float* sv = d.saved + (long)b * d.saved_ld + j;
+      sv[0] = z; sv[H] = r; sv[2L * H] = hh; sv[3L * H] = arh;
+    }
+  } else {
+    hn = tanhf_(pre[0] + s[0]);
+    if (d.saved) d.saved[(long)b * d.saved_ld + j] = hn;
+  }
+  if (d.h_out) d.h_out[(long)b * d.h_out_ld + j] = m ? hn : hp;
+  if (d.y_out) d.y_out[(long)b * d.y_out_ld + j] = m ? hn : yp;
+}
+
+// ------------------------------------------------------------------------------------------ backward step
+struct BwdDir {
+  int KSt, NT;             // packed K steps; slab n-tiles (NT*16 >= 4*KSt)
+  const float* Wpb;
+  // gradient wrt the state h leaving this cell:  sum_q slabA[q][b][colA + j]  +  addA[b][j]
+  const float* slabA; int QA; long slabA_qstride; long slabA_ld; int colA;
+  const float* addA; long addA_ld;
+  // gradient wrt the emitted output y:           sum_q slabB[q][b][colB + j]  +  addB[b][j]
+  const float* slabB; int QB; long slabB_qstride; long slabB_ld; int colB;
+  const float* addB; long addB_ld;
+  float* dc; long dc_ld;               // cell-state gradient, updated in place (LSTM)
+  float* dy_carry; long dy_carry_ld;   // pending output gradient of masked steps (sequence use), may be null
+  const uint8_t* mask; long mask_ld;
+  const float* saved; long saved_ld;   // activations saved by the forward step
+  const float* h_prev; long h_prev_ld; // GRU
+  const float* c_prev; long c_prev_ld; // LSTM
+  const float* c_out; long c_out_ld;   // LSTM: c after this step
+  float* dslots; long dslots_ld;       // [B][NS*H] gradient wrt the gate pre-activation sums (may alias saved)
+  float* slab_out; long slab_out_qstride; long slab_out_ld;  // [Q][Bpad][NT*16]
+  int hcol;                // first packed column of the recurrent segment
+};
+struct BwdArgs { BwdDir d[2]; int B, H; };
+
+template <int CELL>
+__global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
+  __shared__ float red[4][64];
+  __shared__ float dp[16 * 17];
+  __shared__ float direct[16 * 4];
+  const BwdDir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int q = blockIdx.x, b0 = blockIdx.y * 16;
+  const int H = a.H, B = a.B;
+  const int bi = lane >> 2, u = lane & 3;
+  const int b = b0 + bi, j = 4 * q + u;
+  const bool live = b < B && j < H;
+
+  // 1. slab reduction, spread over the 4 waves: wave w sums q' = w, w+4, ...   (dh in .x, dy in .y)
+  float sa = 0.f, sb = 0.f;
+  if (live) {
+    if (d.slabA) for (int qq = wave; qq < d.QA; qq += 4) sa += d.slabA[(long)qq * d.slabA_qstride + (long)b * d.slabA_ld + d.colA + j];
+    if (d.slabB) for (int qq = wave; qq < d.QB; qq += 4) sb += d.slabB[(long)qq * d.slabB_qstride + (long)b * d.slabB_ld + d.colB + j];
+  }
+  red[wave][lane] = sa;
+  __syncthreads();
+  float dh_state = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  __syncthreads();
+  red[wave][lane] = sb;
+  __syncthreads();
+  float dy = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+
+  // 2. gate gradients (wave 0)
+  if (wave == 0) {
+    float ds[4] = {0.f, 0.f, 0.f, 0.f};
+    float dir = 0.f;
+    if (live) {
+      if (d.addA) dh_state += d.addA[(long)b * d.addA_ld + j];
+      if (d.addB) dy += d.addB[(long)b * d.addB_ld + j];
+      const bool m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+      float carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
+      if (!m) {
+        dir = dh_state;                       // state carried unchanged
+        if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = carry + dy;
+        // dc stays as it is
+      } else {
+        const float dh = dh_state + dy + carry;
+        if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = 0.f;
+        const float* sv = d.saved + (long)b * d.saved_ld + j;
+        if (CELL == CELL_LSTM) {
+          const float ig = sv[0], fg = sv[H], gg = sv[2L * H], og = sv[3L * H];
+          const float cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+          const float tc = tanhf_(d.c_out[(long)b * d.c_out_ld + j]);
+          float* dcp = d.dc + (long)b * d.dc_ld + j;
+          const float dct = *dcp + dh * og * (1.f - tc * tc);
+          ds[0] = dct * gg * ig * (1.f - ig);
+          ds[1] = dct * cp * fg * (1.f - fg);
+          ds[2] = dct * ig * (1.f - gg * gg);
+          ds[3] = dh * tc * og * (1.f - og);
+          *dcp = dct * fg;
+        } else if (CELL == CELL_GRU) {
+          const float z = sv[0], r = sv[H], hh = sv[2L * H], arh = sv[3L * H];
+          const float hp = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+          const float dahh = dh * (1.f - z) * (1.f - hh * hh);
+          ds[0] = dh * (hp - hh) * z * (1.f - z);
+          ds[1] = dahh * arh * r * (1.f - r);
+          ds[2] = dahh;
+          ds[3] = dahh * r;
+          dir = dh * z;
+        } else {
+          const float hn = sv[0];
+          ds[0] = dh * (1.f - hn * hn);
+        }
+      }
+      constexpr int NS = CELL == CELL_RNN ? 1 : 4;
+      float* o = d.dslots + (long)b * d.dslots_ld + j;
+#pragma unroll
+      for (int g = 0; g < NS; ++g) o[(long)g * H] = ds[g];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dp[bi * 17 + g * 4 + u] = ds[g];
+    direct[bi * 4 + u] = dir;
+  }
+  __syncthreads();
+
+  // 3. partial product dA[16 x Ktot] = dslots[16 x 16] x Wslice^T  -> slab (plus the direct term)
+  if (d.slab_out == nullptr) return;
+  float av[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) av[s4] = dp[li * 17 + 4 * s4 + lq];
+  for (int nt = wave; nt < d.NT; nt += 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wb = d.Wpb + ((long)q * d.NT + nt) * 4 * 64 + lane;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], wb[s4 * 64], acc, 0, 0, 0);
+    const int col = nt * 16 + li;
+    const int own = col - d.hcol - 4 * q;  // 0..3 when this column is one of the owned units' h columns
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = lq * 4 + r;
+      float v = acc[r];
+      if (own >= 0 && own < 4) v += direct[row * 4 + own];
+      d.slab_out[(long)q * d.slab_out_qstride + (long)(b0 + row) * d.slab_out_ld + col] = v;
+    }
+  }
+}
+
+// sum of slabs: out[b][c] (+)= sum_q slab[q][b][col0 + c] (+ add[b][c])
+__global__ void slab_reduce_kernel(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B,
+                                   const float* add, long add_ld, float* out, long out_ld, int accumulate) {
+  const long n = (long)B * ncols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ncols), c = (int)(i % ncols);
+    float s = 0.f;
+    for (int q = 0; q < Q; ++q) s += slab[(long)q * qstride + (long)b * ld + col0 + c];
+    if (add) s += add[(long)b * add_ld + c];
+    float* o = out + (long)b * out_ld + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int cell_from_name(int rnn_type) { return rnn_type; }
+
+extern "C" int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr_rnn_geom* g) {
+  ASR_CHECK(g && K, ASR_ERR_ARG, "asr_rnn_geometry: null argument");
+  ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
+  ASR_CHECK(nseg >= 1 && nseg <= ASR_RNN_MAXSEG && H > 0, ASR_ERR_SHAPE, "asr_rnn_geometry: nseg %d / H %d", nseg, H);
+  g->Q = asr_cdiv(H, 4);
+  int ks = 0;
+  for (int i = 0; i < ASR_RNN_MAXSEG; ++i) g->ks0[i] = 0;
+  for (int i = 0; i < nseg; ++i) { g->ks0[i] = ks; ks += asr_cdiv(K[i], 4); }
+  g->KSt = ks;
+  g->NT = asr_cdiv(4L * ks, 16);
+  g->wp_floats = (long)g->Q * g->KSt * 64;
+  g->wpb_floats = (long)g->Q * g->NT * 4 * 64;
+  g->slab_ld = g->NT * 16;
+  return ASR_OK;
+}
+
+extern "C" int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const long* ldw, const int* K,
+                            const int* is_rec, float* Wp, float* Wpb, void* stream) {
+  ASR_CHECK(W && ldw && K && is_rec && Wp && Wpb, ASR_ERR_ARG, "asr_rnn_pack: null argument");
+  asr_rnn_geom g;
+  int rc = asr_rnn_geometry(rnn_type, H, nseg, K, &g);
+  if (rc) return rc;
+  PackArgs a{};
+  for (int i = 0; i < nseg; ++i) { a.W[i] = W[i]; a.ldw[i] = ldw[i]; a.K[i] = K[i]; a.ks0[i] = g.ks0[i]; a.is_rec[i] = is_rec[i]; }
+  a.nseg = nseg; a.KSt = g.KSt; a.NT = g.NT; a.H = H; a.Q = g.Q; a.cell = cell_from_name(rnn_type); a.Wp = Wp; a.Wpb = Wpb;
+  const long n = g.wp_floats + g.wpb_floats;
+  hipLaunchKernelGGL(rnn_pack_kernel, dim3((unsigned)min((long)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+static void fill_fwd_dir(FwdDir* d, const asr_rnn_step_fwd* s) {
+  *d = FwdDir{};
+  d->nseg = s->nseg; d->KSt = s->KSt; d->Wp = s->Wp;
+  for (int i = 0; i < s->nseg; ++i) {
+    d->seg[i].x = s->seg_x[i]; d->seg[i].ld = s->seg_ld[i]; d->seg[i].K = s->seg_K[i]; d->seg[i].ks0 = s->seg_ks0[i];
+    d->seg[i].drop = s->seg_drop_rate[i] > 0.f; d->seg[i].drop_stream = s->seg_drop_stream[i];
+    d->seg[i].drop_rate = s->seg_drop_rate[i]; d->seg[i].drop_ld = s->seg_drop_ld[i]; d->seg[i].drop_off = s->seg_drop_off[i];
+  }
+  d->pre = s->pre; d->pre_ld = s->pre_ld; d->bias = s->bias; d->bias_rec = s->bias_rec;
+  d->h_prev = s->h_prev; d->h_prev_ld = s->h_prev_ld; d->c_prev = s->c_prev; d->c_prev_ld = s->c_prev_ld;
+  d->y_prev = s->y_prev; d->y_prev_ld = s->y_prev_ld; d->mask = s->mask; d->mask_ld = s->mask_ld;
+  d->h_out = s->h_out; d->h_out_ld = s->h_out_ld; d->c_out = s->c_out; d->c_out_ld = s->c_out_ld;
+  d->y_out = s->y_out; d->y_out_ld = s->y_out_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
+}
+
+static int launch_fwd(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) {
+  dim3 grid((unsigned)asr_cdiv(a.H, 4), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_fwd_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_step_fwd_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(rnn_step_fwd_kernel<CELL_RNN>, grid, dim3(256), 0, st, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fwd* steps, const uint32_t* seed,
+                                void* stream) {
+  ASR_CHECK(steps, ASR_ERR_ARG, "asr_rnn_cell_fwd: null argument");
+  ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
+  ASR_CHECK(B > 0 && H > 0 && (ndir == 1 || ndir == 2), ASR_ERR_SHAPE, "asr_rnn_cell_fwd: B %d H %d ndir %d", B, H, ndir);
+  FwdArgs a{};
+  a.B = B; a.H = H; a.seed = seed;
+  for (int i = 0; i < ndir; ++i) {
+    ASR_CHECK(steps[i].nseg >= 1 && steps[i].nseg <= ASR_RNN_MAXSEG && steps[i].Wp, ASR_ERR_ARG, "asr_rnn_cell_fwd: bad segments");
+    fill_fwd_dir(&a.d[i], &steps[i]);
+    for (int s = 0; s < steps[i].nseg; ++s)
+      ASR_CHECK(!(a.d[i].seg[s].drop && !seed), ASR_ERR_ARG, "asr_rnn_cell_fwd: dropout needs a device seed");
+  }
+  return launch_fwd(rnn_type, a, ndir, (hipStream_t)stream);
+}
+
+// Whole BiRNN layer forward: T dependent step launches, both directions per launch (las.py:108-126).
+extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
+  ASR_CHECK(s, ASR_ERR_ARG, "asr_rnn_seq_fwd: null argument");
+  ASR_CHECK(s->rnn_type >= 0 && s->rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", s->rnn_type);
+  ASR_CHECK(s->B > 0 && s->T > 0 && s->H > 0 && (s->ndir == 1 || s->ndir == 2), ASR_ERR_SHAPE, "asr_rnn_seq_fwd: bad B/T/H/ndir");
+  const int B = s->B, T = s->T, H = s->H;
+  const int NG = cell_ngates(s->rnn_type), NS = cell_nsaved(s->rnn_type);
+  const bool lstm = s->rnn_type == CELL_LSTM;
+  asr_rnn_geom g;
+  int K1[1] = {H};
+  asr_rnn_geometry(s->rnn_type, H, 1, K1, &g);
+  for (int d = 0; d < s->ndir; ++d) {
+    ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_seq_fwd: null buffer (dir %d)", d);
+    ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_seq_fwd: recurrent dropout is not supported");
+  }
+  for (int step = 0; step < T; ++step) {
+    FwdArgs a{};
+    a.B = B; a.H = H; a.seed = nullptr;
+    for (int d = 0; d < s->ndir; ++d) {
+      const bool rev = s->reverse[d] != 0;
+      const int t = rev ? T - 1 - step : step;
+      const int tp = rev ? t + 1 : t - 1;  // time index of the previous processing step
+      FwdDir& fd = a.d[d];
+      fd = FwdDir{};
+      fd.nseg = 1; fd.KSt = g.KSt; fd.Wp = s->Wp[d];
+      fd.pre = s->pre[d] + (long)t * NG * H; fd.pre_ld = (long)T * NG * H;
+      fd.bias = nullptr; fd.bias_rec = s->bias_rec[d];
+      float* hseq = s->hseq[d];
+      float* cseq = s->cseq[d];
+      if (step == 0) {
+        fd.h_prev = s->h0[d]; fd.h_prev_ld = s->h0_ld[d];
+        fd.c_prev = lstm ? s->c0[d] : nullptr; fd.c_prev_ld = s->c0_ld[d];
+        fd.y_prev = nullptr;
+      } else {
+        fd.h_prev = hseq + (long)tp * H; fd.h_prev_ld = (long)T * H;
+        fd.c_prev = lstm ? cseq + (long)tp * H : nullptr; fd.c_prev_ld = (long)T * H;
+        fd.y_prev = s->y + (long)tp * s->y_ld + s->y_col[d]; fd.y_prev_ld = (long)T * s->y_ld;
+      }
+      fd.seg[0].x = fd.h_prev; fd.seg[0].ld = fd.h_prev_ld; fd.seg[0].K = H; fd.seg[0].ks0 = 0;
+      fd.mask = s->mask ? s->mask + t : nullptr; fd.mask_ld = T;
+      fd.h_out = hseq + (long)t * H; fd.h_out_ld = (long)T * H;
+      fd.c_out = lstm ? cseq + (long)t * H : nullptr; fd.c_out_ld = (long)T * H;
+      fd.y_out = s->y + (long)t * s->y_ld + s->y_col[d]; fd.y_out_ld = (long)T * s->y_ld;
+      fd.saved = s->saved[d] ? s->saved[d] + (long)t * NS * H : nullptr; fd.saved_ld = (long)T * NS * H;
+    }
+    int rc = launch_fwd(s->rnn_type, a, s->ndir, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return ASR_OK;
+}
+
+static void fill_bwd_dir(BwdDir* d, const asr_rnn_step_bwd* s) {
+  *d = BwdDir{};
+  d->KSt = s->KSt; d->NT = s->NT; d->Wpb = s->Wpb;
+  d->slabA = s->slabA; d->QA = s->QA; d->slabA_qstride = s->slabA_qstride; d->slabA_ld = s->slabA_ld; d->colA = s->colA;
+  d->addA = s->addA; d->addA_ld = s->addA_ld;
+  d->slabB = s->slabB; d->QB = s->QB; d->slabB_qstride = s->slabB_qstride; d->slabB_ld = s->slabB_ld; d->colB = s->colB;
+  d->addB = s->addB; d->addB_ld = s->addB_ld;
+  d->dc = s->dc; d->dc_ld = s->dc_ld; d->dy_carry = s->dy_carry; d->dy_carry_ld = s->dy_carry_ld;
+  d->mask = s->mask; d->mask_ld = s->mask_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
+  d->h_prev = s->h_prev; d->h_prev_ld = s->h_prev_ld; d->c_prev = s->c_prev; d->c_prev_ld = s->c_prev_ld;
+  d->c_out = s->c_out; d->c_out_ld = s->c_out_ld; d->dslots = s->dslots; d->dslots_ld = s->dslots_ld;
+  d->slab_out = s->slab_out; d->slab_out_qstride = s->slab_out_qstride; d->slab_out_ld = s->slab_out_ld; d->hcol = s->hcol;
+}
+
+static int launch_bwd(int rnn_type, const BwdArgs& a, int ndir, hipStream_t st) {
+  dim3 grid((unsigned)asr_cdiv(a.H, 4), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_RNN>, grid, dim3(256), 0, st, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, void* stream) {
+  ASR_CHECK(steps, ASR_ERR_ARG, "asr_rnn_cell_bwd: null argument");
+  ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
+  ASR_CHECK(B > 0 && H > 0 && (ndir == 1 || ndir == 2), ASR_ERR_SHAPE, "asr_rnn_cell_bwd: B %d H %d ndir %d", B, H, ndir);
+  BwdArgs a{};
+  a.B = B; a.H = H;
+  for (int i = 0; i < ndir; ++i) {
+    ASR_CHECK(steps[i].saved && steps[i].dslots, ASR_ERR_ARG, "asr_rnn_cell_bwd: saved/dslots missing");
+    ASR_CHECK(rnn_type != CELL_LSTM || (steps[i].dc && steps[i].c_out), ASR_ERR_ARG, "asr_rnn_cell_bwd: LSTM needs dc and c_out");
+    ASR_CHECK(!steps[i].slab_out || steps[i].Wpb, ASR_ERR_ARG, "asr_rnn_cell_bwd: slab_out needs Wpb");
+    fill_bwd_dir(&a.d[i], &steps[i]);
+  }
+  return launch_bwd(rnn_type, a, ndir, (hipStream_t)stream);
+}
+
+// Whole BiRNN layer backward-through-time.  On return:
+//   saved[d] holds dslots (gradient wrt the gate sums) for the batched dW / dU / dX GEMMs,
+//   dh0[d] / dc0[d] hold the gradient wrt the initial states (if non-null).
+extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs, void* stream) {
+  ASR_CHECK(s && gs, ASR_ERR_ARG, "asr_rnn_seq_bwd: null argument");
+  ASR_CHECK(s->rnn_type >= 0 && s->rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", s->rnn_type);
+  const int B = s->B, T = s->T, H = s->H;
+  const int NS = cell_nsaved(s->rnn_type);
+  const bool lstm = s->rnn_type == CELL_LSTM;
+  asr_rnn_geom g;
+  int K1[1] = {H};
+  asr_rnn_geometry(s->rnn_type, H, 1, K1, &g);
+  const int Bpad = asr_cdiv(B, 16) * 16;
+  const long qstride = (long)Bpad * g.slab_ld;
+  const long slab_floats = (long)g.Q * qstride;
+  for (int d = 0; d < s->ndir; ++d) {
+    ASR_CHECK(s->saved[d] && s->Wpb[d] && gs->slab[d] && gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(!lstm || gs->dc[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: LSTM needs a dc buffer (dir %d)", d);
+    ASR_CHECK(!s->mask || gs->dy_carry[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: masked sequences need dy_carry (dir %d)", d);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int step = T - 1; step >= 0; --step) {
+    BwdArgs a{};
+    a.B = B; a.H = H;
+    for (int d = 0; d < s->ndir; ++d) {
+      const bool rev = s->reverse[d] != 0;
+      const int t = rev ? T - 1 - step : step;
+      const int tp = rev ? t + 1 : t - 1;
+      BwdDir& bd = a.d[d];
+      bd = BwdDir{};
+      bd.KSt = g.KSt; bd.NT = g.NT; bd.Wpb = s->Wpb[d];
+      float* slab_cur = gs->slab[d] + (long)(step & 1) * slab_floats;        // written by this step
+      const float* slab_nxt = gs->slab[d] + (long)((step + 1) & 1) * slab_floats;  // written by step+1
+      if (step == T - 1) {
+        bd.slabA = nullptr; bd.addA = gs->dh_last[d]; bd.addA_ld = gs->dh_last_ld[d];
+      } else {
+        bd.slabA = slab_nxt; bd.QA = g.Q; bd.slabA_qstride = qstride; bd.slabA_ld = g.slab_ld; bd.colA = 0;
+      }
+      bd.slabB = nullptr;
+      bd.addB = gs->dy + (long)t * gs->dy_ld + s->y_col[d]; bd.addB_ld = (long)T * gs->dy_ld;
+      bd.dc = lstm ? gs->dc[d] : nullptr; bd.dc_ld = H;
+      bd.dy_carry = s->mask ? gs->dy_carry[d] : nullptr; bd.dy_carry_ld = H;
+      bd.mask = s->mask ? s->mask + t : nullptr; bd.mask_ld = T;
+      bd.saved = s->saved[d] + (long)t * NS * H; bd.saved_ld = (long)T * NS * H;
+      if (step == 0) {
+        bd.h_prev = s->h0[d]; bd.h_prev_ld = s->h0_ld[d];
+        bd.c_prev = lstm ? s->c0[d] : nullptr; bd.c_prev_ld = s->c0_ld[d];
+      } else {
+        bd.h_prev = s->hseq[d] + (long)tp * H; bd.h_prev_ld = (long)T * H;
+        bd.c_prev = lstm ? s->cseq[d] + (long)tp * H : nullptr; bd.c_prev_ld = (long)T * H;
+      }
+      bd.c_out = lstm ? s->cseq[d] + (long)t * H : nullptr; bd.c_out_ld = (long)T * H;
+      bd.dslots = s->saved[d] + (long)t * NS * H; bd.dslots_ld = (long)T * NS * H;
+      bd.slab_out = slab_cur; bd.slab_out_qstride = qstride; bd.slab_out_ld = g.slab_ld; bd.hcol = 0;
+    }
+    int rc = launch_bwd(s->rnn_type, a, s->ndir, st);
+    if (rc) return rc;
+  }
+  // gradient wrt the initial state = sum of the slabs written by step 0
+  for (int d = 0; d < s->ndir; ++d) {
+    if (gs->dh0[d]) {
+      const float* slab0 = gs->slab[d];  // step 0 -> parity 0
+      const long n = (long)B * H;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, st, slab0, g.Q,
+                         qstride, (long)g.slab_ld, 0, H, B, (const float*)nullptr, 0L, gs->dh0[d], gs->dh0_ld[d], 0);
+    }
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
+                               long add_ld, float* out, long out_ld, int accumulate, void* stream) {
+  ASR_CHECK(slab && out && Q > 0 && B > 0 && ncols > 0, ASR_ERR_ARG, "asr_slab_reduce: bad argument");
+  const long n = (long)B * ncols;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab,
+                     Q, qstride, ld, col0, ncols, B, add, add_ld, out, out_ld, accumulate);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

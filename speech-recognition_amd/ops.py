@@ -1,0 +1,229 @@
+"""Thin tensor-level wrappers over the C ABI (include/asr_mi355x.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every computation below
+is a hand-written gfx950 kernel inside libasr_mi355x.so.  All wrappers launch on
+``torch.cuda.current_stream()`` and never synchronise.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import RNN_TYPES, check
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (speech_recognition_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def rnn_type_id(rnn_type: str) -> int:
+    if rnn_type not in RNN_TYPES:
+        raise ValueError(f"rnn_type: {rnn_type} is invalid!")  # same message as las.py:17
+    return RNN_TYPES[rnn_type]
+
+
+# ----------------------------------------------------------------------------------------- front end
+class LogmelPlan:
+    """Constant tables of the fused front-end kernel for one DataConfig (built once, on host in
+    float64 inside the library, uploaded once)."""
+
+    def __init__(self, sample_rate, frame_length, frame_step, fft_length, num_mel_bins=80, lower_edge_hertz=80.0,
+                 upper_edge_hertz=7600.0, epsilon=1e-12, use_delta=True, spec_augment=None, device="cuda"):
+        sa = spec_augment or {}
+        if sa.get("W"):
+            raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
+        enable = bool(spec_augment) and bool(sa.get("enable", True))
+        use_f = bool(sa.get("F")) and bool(sa.get("m_F"))
+        use_t = bool(sa.get("T")) and bool(sa.get("p")) and bool(sa.get("m_T"))
+        self.cfg = _lib.LogmelCfg(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, lower_edge_hertz,
+                                  upper_edge_hertz, epsilon, 1 if use_delta else 0, 1 if enable else 0,
+                                  int(sa.get("F") or 0) if use_f else 0, int(sa.get("m_F") or 0) if use_f else 0,
+                                  int(sa.get("T") or 0) if use_t else 0, int(sa.get("m_T") or 0) if use_t else 0,
+                                  float(sa.get("p") or 0.0) if use_t else 0.0)
+        n1, n2, n3 = C.c_long(), C.c_long(), C.c_long()
+        check(lib().asr_logmel_table_sizes(C.byref(self.cfg), C.byref(n1), C.byref(n2), C.byref(n3)))
+        tw = np.empty(n1.value, np.float32)
+        mw = np.empty(n2.value, np.float32)
+        mr = np.empty(n3.value, np.int32)
+        check(lib().asr_logmel_build_tables(C.byref(self.cfg), tw.ctypes.data_as(C.c_void_p), mw.ctypes.data_as(C.c_void_p),
+                                            mr.ctypes.data_as(C.c_void_p)))
+        self.melw_host = mw.reshape(fft_length // 2 + 1, num_mel_bins)
+        self.tw = torch.from_numpy(tw).to(device)
+        self.melw = torch.from_numpy(mw).to(device)
+        self.melrange = torch.from_numpy(mr).to(device)
+        self.channels = 3 if use_delta else 1
+        self.num_mel_bins = num_mel_bins
+        self.frame_length, self.frame_step = frame_length, frame_step
+
+    def num_frames(self, n_samples: int) -> int:
+        return 0 if n_samples < self.frame_length else 1 + (n_samples - self.frame_length) // self.frame_step
+
+    def __call__(self, audio: torch.Tensor, n_samples: torch.Tensor, T_out: int, seed: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """audio [B, n_max] f32, n_samples [B] i32 -> [B, T_out, mel, C] f32 (zero beyond each clip)."""
+        _dev(audio, name="audio")
+        _dev(n_samples, torch.int32, "n_samples")
+        _dev(seed, torch.int32, "seed")
+        B, n_max = audio.shape
+        if out is None:
+            out = torch.empty(B, T_out, self.num_mel_bins, self.channels, device=audio.device, dtype=torch.float32)
+        assert audio.is_contiguous() and out.is_contiguous()
+        check(lib().asr_logmel_features(C.byref(self.cfg), _p(audio), _p(n_samples), B, n_max, _p(self.tw), _p(self.melw),
+                                        _p(self.melrange), _p(seed), _p(out), T_out, _stream()))
+        return out
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+def _mat(t, name):
+    _dev(t, name=name)
+    if t.dim() not in (2, 3) or t.stride(-1) != 1:
+        raise ValueError(f"{name}: need a 2-D/3-D tensor with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t
+
+
+def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias=None, relu=False, a_scale=None,
+         a_rpg=0, c_scale=None, c_rpg=0):
+    """c (+)= alpha * op(a) @ op(b) (+ bias).  2-D operands, or 3-D with a leading batch axis; a 2-D `c`
+    with 3-D a/b means split-K over the batch axis (atomic accumulation, requires accumulate)."""
+    _mat(a, "a"), _mat(b, "b"), _mat(c, "c")
+    batch = a.shape[0] if a.dim() == 3 else 1
+    if b.dim() == 3 and a.dim() == 3:
+        assert b.shape[0] == batch
+    am, ak = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    bk, bn = (b.shape[-1], b.shape[-2]) if trans_b else (b.shape[-2], b.shape[-1])
+    if ak != bk or c.shape[-2] != am or c.shape[-1] != bn:
+        raise ValueError(f"gemm shape mismatch: op(a) [{am},{ak}] op(b) [{bk},{bn}] c {tuple(c.shape)}")
+    d = _lib.GemmDesc()
+    d.trans_a, d.trans_b = int(trans_a), int(trans_b)
+    d.M, d.N, d.K, d.batch = am, bn, ak, batch
+    d.lda, d.ldb, d.ldc = a.stride(-2), b.stride(-2), c.stride(-2)
+    d.stride_a = a.stride(0) if a.dim() == 3 else 0
+    d.stride_b = b.stride(0) if b.dim() == 3 else 0
+    d.stride_c = c.stride(0) if c.dim() == 3 else 0
+    d.stride_a_scale = 0
+    d.alpha = alpha
+    d.accumulate = int(accumulate)
+    if batch > 1 and c.dim() == 2:
+        if not accumulate:
+            raise ValueError("split-K gemm (2-D c, batched a/b) accumulates atomically: pass accumulate=1 and pre-zero c")
+        d.accumulate = 2
+    d.relu = int(relu)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    d.a_rpg = int(a_rpg)
+    d.c_scale = c_scale.data_ptr() if c_scale is not None else None
+    d.c_rpg = int(c_rpg)
+    check(lib().asr_gemm_f32(C.byref(d), _p(a), _p(b), _p(c), _stream()))
+    return c
+
+
+# ----------------------------------------------------------------------------------------- recurrent layers
+def rnn_geometry(rnn_type: str, H: int, Ks: Sequence[int]) -> _lib.RnnGeom:
+    g = _lib.RnnGeom()
+    arr = (C.c_int * len(Ks))(*Ks)
+    check(lib().asr_rnn_geometry(rnn_type_id(rnn_type), H, len(Ks), arr, C.byref(g)))
+    return g
+
+
+class PackedCell:
+    """MFMA-fragment-order image of the weights multiplying a cell's concatenated inputs.
+    `weights`: list of (W [K_i, G*H] view with unit inner stride, is_recurrent)."""
+
+    def __init__(self, rnn_type: str, H: int, Ks: Sequence[int], device="cuda"):
+        self.rnn_type, self.H, self.Ks = rnn_type, H, list(Ks)
+        self.geom = rnn_geometry(rnn_type, H, Ks)
+        self.Wp = torch.empty(self.geom.wp_floats, device=device, dtype=torch.float32)
+        self.Wpb = torch.empty(self.geom.wpb_floats, device=device, dtype=torch.float32)
+
+    def pack(self, weights):
+        n = len(weights)
+        assert n == len(self.Ks)
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for w, _ in weights])
+        ld = (C.c_long * n)(*[w.stride(0) for w, _ in weights])
+        K = (C.c_int * n)(*self.Ks)
+        rec = (C.c_int * n)(*[int(r) for _, r in weights])
+        for (w, _), k in zip(weights, self.Ks):
+            _dev(w, name="weight")
+            assert w.shape[0] == k and w.stride(1) == 1
+        check(lib().asr_rnn_pack(rnn_type_id(self.rnn_type), self.H, n, Wp, ld, K, rec, _p(self.Wp), _p(self.Wpb), _stream()))
+        return self
+
+
+def _arr2(vals, ctype=C.c_void_p):
+    vals = list(vals) + [None] * (2 - len(vals))
+    if ctype is C.c_void_p:
+        return (C.c_void_p * 2)(*[None if v is None else (v.data_ptr() if isinstance(v, torch.Tensor) else v) for v in vals])
+    return (ctype * 2)(*[0 if v is None else v for v in vals])
+
+
+def make_rnn_seq(rnn_type, B, T, H, dirs, mask, y, y_cols):
+    """dirs: list (1 or 2) of dicts with keys pre, cell(PackedCell), bias_rec, h0, c0, hseq, cseq, saved, reverse."""
+    s = _lib.RnnSeq()
+    s.rnn_type, s.B, s.T, s.H, s.ndir = rnn_type_id(rnn_type), B, T, H, len(dirs)
+    s.reverse = (C.c_int * 2)(*([int(d.get("reverse", False)) for d in dirs] + [0] * (2 - len(dirs))))
+    s.pre = _arr2([d["pre"] for d in dirs])
+    s.Wp = _arr2([d["cell"].Wp for d in dirs])
+    s.Wpb = _arr2([d["cell"].Wpb for d in dirs])
+    s.bias_rec = _arr2([d.get("bias_rec") for d in dirs])
+    s.h0 = _arr2([d.get("h0") for d in dirs])
+    s.h0_ld = _arr2([d["h0"].stride(0) if d.get("h0") is not None else 0 for d in dirs], C.c_long)
+    s.c0 = _arr2([d.get("c0") for d in dirs])
+    s.c0_ld = _arr2([d["c0"].stride(0) if d.get("c0") is not None else 0 for d in dirs], C.c_long)
+    s.rec_mult = _arr2([None for _ in dirs])
+    s.mask = mask.data_ptr() if mask is not None else None
+    s.hseq = _arr2([d["hseq"] for d in dirs])
+    s.cseq = _arr2([d.get("cseq") for d in dirs])
+    s.y = y.data_ptr()
+    s.y_ld = y.stride(1)
+    s.y_col = (C.c_int * 2)(*(list(y_cols) + [0] * (2 - len(y_cols))))
+    s.saved = _arr2([d.get("saved") for d in dirs])
+    return s
+
+
+def rnn_seq_fwd(seq):
+    check(lib().asr_rnn_seq_fwd(C.byref(seq), _stream()))
+
+
+def rnn_seq_bwd(seq, dy, dirs_grad):
+    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, slab, dh0."""
+    g = _lib.RnnSeqGrad()
+    g.dy = dy.data_ptr()
+    g.dy_ld = dy.stride(1)
+    g.dh_last = _arr2([d.get("dh_last") for d in dirs_grad])
+    g.dh_last_ld = _arr2([d["dh_last"].stride(0) if d.get("dh_last") is not None else 0 for d in dirs_grad], C.c_long)
+    g.dc = _arr2([d.get("dc") for d in dirs_grad])
+    g.dy_carry = _arr2([d.get("dy_carry") for d in dirs_grad])
+    g.slab = _arr2([d["slab"] for d in dirs_grad])
+    g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
+    g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
+    check(lib().asr_rnn_seq_bwd(C.byref(seq), C.byref(g), _stream()))
+
+
+def slab_floats(geom, B):
+    return geom.Q * ((B + 15) // 16 * 16) * geom.slab_ld
+
+
+def slab_reduce(slab, geom, B, col0, ncols, out, add=None, accumulate=False):
+    Bpad = (B + 15) // 16 * 16
+    check(lib().asr_slab_reduce(_p(slab), geom.Q, Bpad * geom.slab_ld, geom.slab_ld, col0, ncols, B, _p(add),
+                                add.stride(0) if add is not None else 0, _p(out), out.stride(0), int(accumulate), _stream()))
+    return out

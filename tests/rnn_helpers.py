@@ -1,0 +1,95 @@
+"""Drive the HIP (Bi)RNN layer kernels from plain tensors (shared by GPU tests)."""
+import torch
+
+from tests.util import gpu
+
+NG = {"lstm": 4, "gru": 3, "rnn": 1}
+NS = {"lstm": 4, "gru": 4, "rnn": 1}
+
+
+class HipBiRNN:
+    """Runs asr_rnn_seq_fwd / asr_rnn_seq_bwd for one BiRNN layer given CPU float64 weights."""
+
+    def __init__(self, rnn_type, x, mask, fwd, bwd, init_states=None, ndir=2):
+        from speech_recognition_amd import ops
+        self.ops, self.rt = ops, rnn_type
+        B, T, D = x.shape
+        H = fwd[1].shape[0]
+        self.B, self.T, self.H, self.D = B, T, H, D
+        ng, ns = NG[rnn_type], NS[rnn_type]
+        self.params = [fwd, bwd][:ndir]
+        self.x = x
+        self.mask = None if mask is None else mask.to(torch.uint8).cuda().contiguous()
+        self.y = torch.zeros(B, T, ndir * H, device="cuda")
+        self.dirs = []
+        nst = 2 if rnn_type == "lstm" else 1
+        for d, (W, U, b) in enumerate(self.params):
+            b_in = b[0] if rnn_type == "gru" else b
+            pre = gpu((x.double() @ W.double() + b_in.double()).float())
+            cell = ops.PackedCell(rnn_type, H, [H]).pack([(gpu(U), True)])
+            dd = dict(pre=pre, cell=cell, reverse=(d == 1), hseq=torch.zeros(B, T, H, device="cuda"),
+                      saved=torch.zeros(B, T, ns * H, device="cuda"))
+            if rnn_type == "lstm":
+                dd["cseq"] = torch.zeros(B, T, H, device="cuda")
+            if rnn_type == "gru":
+                dd["bias_rec"] = gpu(b[1])
+            if init_states is not None:
+                st = init_states[d * nst:(d + 1) * nst]
+                dd["h0"] = gpu(st[0])
+                if rnn_type == "lstm":
+                    dd["c0"] = gpu(st[1])
+            self.dirs.append(dd)
+        self.seq = ops.make_rnn_seq(rnn_type, B, T, H, self.dirs, self.mask, self.y, [d * H for d in range(ndir)])
+
+    def forward(self):
+        self.ops.rnn_seq_fwd(self.seq)
+        states = []
+        for d, dd in enumerate(self.dirs):
+            t_last = 0 if dd["reverse"] else self.T - 1
+            states.append(dd["hseq"][:, t_last])
+            if self.rt == "lstm":
+                states.append(dd["cseq"][:, t_last])
+        return self.y, states
+
+    def backward(self, dy, dstates):
+        """dy [B,T,ndir*H]; dstates: list like the states list (or None entries). Returns dict of grads."""
+        ops, B, T, H = self.ops, self.B, self.T, self.H
+        nst = 2 if self.rt == "lstm" else 1
+        geom = self.dirs[0]["cell"].geom
+        gds = []
+        for d, dd in enumerate(self.dirs):
+            st = dstates[d * nst:(d + 1) * nst]
+            g = dict(slab=torch.zeros(2 * ops.slab_floats(geom, B), device="cuda"),
+                     dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"))
+            if st[0] is not None:
+                g["dh_last"] = gpu(st[0])
+            if self.rt == "lstm":
+                g["dc"] = gpu(st[1]) if st[1] is not None else torch.zeros(B, H, device="cuda")
+            gds.append(g)
+        ops.rnn_seq_bwd(self.seq, gpu(dy), gds)
+        out = []
+        for d, (dd, g) in enumerate(zip(self.dirs, gds)):
+            W, U, b = [p.double() for p in self.params[d]]
+            ds = dd["saved"].double().cpu()                       # [B,T,NS*H] gate-sum gradients
+            hseq = dd["hseq"].double().cpu()
+            h0 = dd["h0"].double().cpu() if "h0" in dd else torch.zeros(B, H, dtype=torch.float64)
+            if dd["reverse"]:
+                hprev = torch.cat([hseq[:, 1:], h0[:, None]], dim=1)
+            else:
+                hprev = torch.cat([h0[:, None], hseq[:, :-1]], dim=1)
+            if self.rt == "gru":
+                dpx = ds[..., :3 * H]
+                drec = torch.cat([ds[..., :2 * H], ds[..., 3 * H:]], dim=-1)
+            else:
+                dpx = drec = ds
+            x = self.x.double()
+            r = dict(dW=torch.einsum("btd,btg->dg", x, dpx), dU=torch.einsum("bth,btg->hg", hprev, drec),
+                     dx=dpx @ W.T, dh0=g["dh0"].double().cpu())
+            if self.rt == "gru":
+                r["db"] = torch.stack([dpx.sum((0, 1)), drec.sum((0, 1))])
+            else:
+                r["db"] = dpx.sum((0, 1))
+            if self.rt == "lstm":
+                r["dc0"] = g["dc"].double().cpu()
+            out.append(r)
+        return out

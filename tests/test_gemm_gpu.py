@@ -1,0 +1,85 @@
+"""GPU parity: asr_gemm_f32 vs float64 matmul (exact-f32 MFMA => ~1e-6 relative)."""
+import pytest
+import torch
+
+from tests.util import assert_close, gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from speech_recognition_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (7968 // 8, 512, 608), (33, 77, 19), (1, 1, 1), (300, 32, 27),
+                                   (16, 1000, 256), (250, 130, 5)])
+def test_gemm_all_layouts(ta, tb, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g, dtype=torch.float64)
+    B = torch.randn((N, K) if tb else (K, N), generator=g, dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    ref = (A.T if ta else A) @ (B.T if tb else B) * 0.5 + bias
+    a, b, bi = gpu(A), gpu(B), gpu(bias)
+    c = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(a, b, c, trans_a=bool(ta), trans_b=bool(tb), alpha=0.5, bias=bi)
+    assert_close(c, ref, 2e-6, f"gemm ta={ta} tb={tb} {M}x{N}x{K}")
+
+
+def test_gemm_strided_views_accumulate_relu_scales():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K, rpg = 96, 80, 52, 12
+    Abig = torch.randn(M, K + 9, generator=g, dtype=torch.float64)
+    Bbig = torch.randn(K, N + 4, generator=g, dtype=torch.float64)
+    A, B = Abig[:, 3:3 + K], Bbig[:, 1:1 + N]
+    asc = torch.rand(M // rpg, K, generator=g, dtype=torch.float64)
+    csc = torch.rand(M // rpg, N, generator=g, dtype=torch.float64)
+    C0 = torch.randn(M, N, generator=g, dtype=torch.float64)
+    Asc = A * asc.repeat_interleave(rpg, 0)
+    ref = C0 + torch.relu((Asc @ B) * csc.repeat_interleave(rpg, 0))
+    ab, bb = gpu(Abig), gpu(Bbig)
+    c = gpu(C0)
+    # relu applies to the product before accumulation in the epilogue order: alpha, bias, c_scale, relu, then +=
+    ops.gemm(ab[:, 3:3 + K], bb[:, 1:1 + N], c, accumulate=1, relu=True, a_scale=gpu(asc), a_rpg=rpg, c_scale=gpu(csc), c_rpg=rpg)
+    assert_close(c, ref, 2e-6, "strided/scale/relu/accumulate")
+
+
+def test_gemm_batched_and_splitk():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    Z, M, N, K = 5, 70, 48, 36
+    A = torch.randn(Z, K, M, generator=g, dtype=torch.float64)   # trans_a layout
+    B = torch.randn(Z, K, N, generator=g, dtype=torch.float64)
+    ref_b = torch.einsum("zkm,zkn->zmn", A, B)
+    a, b = gpu(A), gpu(B)
+    c = torch.empty(Z, M, N, device="cuda")
+    ops.gemm(a, b, c, trans_a=True)
+    assert_close(c, ref_b, 2e-6, "batched TN")
+    c2 = torch.zeros(M, N, device="cuda")
+    ops.gemm(a, b, c2, trans_a=True, accumulate=1)
+    assert_close(c2, ref_b.sum(0), 4e-6, "split-K over batch (atomic)")
+
+
+def test_gemm_large_tile_path_matches():
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 2048, 2048, 300
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    c = torch.empty(M, N, device="cuda")
+    ops.gemm(gpu(A), gpu(B), c)
+    assert_close(c, A.double() @ B.double(), 3e-6, "128x128 tile path")
+
+
+def test_gemm_rejects_bad_shapes():
+    ops = _ops()
+    a = torch.zeros(4, 5, device="cuda")
+    b = torch.zeros(6, 7, device="cuda")
+    c = torch.zeros(4, 7, device="cuda")
+    with pytest.raises(ValueError):
+        ops.gemm(a, b, c)
+    with pytest.raises(ValueError):
+        ops.gemm(a.cpu(), b, c)

@@ -1,0 +1,91 @@
+"""GPU parity: (Bi)RNN layer kernels (LSTM / GRU / SimpleRNN, arbitrary masks, chained initial
+states) vs the oracle's K.rnn restatement; gradients vs torch.autograd on the float64 oracle.
+Also the reference's own invariant: appending masked padding must not change the prefix
+(reference tests/models/test_las.py:21-44, test_deepspeech2.py:30-56)."""
+import pytest
+import torch
+
+from oracle import layers as L
+from tests.rnn_helpers import NG, HipBiRNN
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def make_params(rt, D, H, g, scale=0.3):
+    ng = NG[rt]
+    out = []
+    for _ in range(2):
+        W = torch.randn(D, ng * H, generator=g, dtype=torch.float64) * scale
+        U = torch.randn(H, ng * H, generator=g, dtype=torch.float64) * scale
+        b = torch.randn((2, ng * H) if rt == "gru" else (ng * H,), generator=g, dtype=torch.float64) * scale
+        out.append((W, U, b))
+    return out
+
+
+CASES = [("lstm", 5, 7, 6, 8), ("lstm", 23, 11, 8, 13), ("gru", 18, 9, 5, 20), ("rnn", 3, 5, 4, 6),
+         ("gru", 34, 6, 3, 111), ("lstm", 32, 40, 16, 256)]
+
+
+@pytest.mark.parametrize("rt,B,T,D,H", CASES)
+@pytest.mark.parametrize("masked,with_init", [(False, False), (True, True)])
+def test_birnn_forward_backward(rt, B, T, D, H, masked, with_init):
+    g = torch.Generator().manual_seed(B * 100 + T * 10 + H)
+    fwd, bwd = make_params(rt, D, H, g)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = (torch.randn(B, T, generator=g) > -0.3) if masked else torch.ones(B, T, dtype=torch.bool)
+    if masked:
+        mask[0] = False           # a fully masked row
+        mask[-1, : T // 2] = False
+    nst = 2 if rt == "lstm" else 1
+    init = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.5 for _ in range(2 * nst)] if with_init else None
+
+    leaves = [t.clone().requires_grad_(True) for p in (fwd, bwd) for t in p]
+    xl = x.clone().requires_grad_(True)
+    il = [t.clone().requires_grad_(True) for t in init] if init else None
+    out, *states = L.birnn(rt, xl, mask, tuple(leaves[:3]), tuple(leaves[3:]), il)
+    R = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    S = [torch.randn(s.shape, generator=g, dtype=torch.float64) for s in states]
+    loss = (out * R).sum() + sum((s * w).sum() for s, w in zip(states, S))
+    loss.backward()
+
+    hip = HipBiRNN(rt, x, mask if masked else None, fwd, bwd, init)
+    y, hstates = hip.forward()
+    assert_close(y, out, 2e-5, "outputs")
+    for i, (a, b_) in enumerate(zip(hstates, states)):
+        assert_close(a, b_, 2e-5, f"state {i}")
+
+    grads = hip.backward(R, S)
+    dx = grads[0]["dx"] + grads[1]["dx"]
+    assert_close(dx, xl.grad, 1e-4, "dx")
+    for d in range(2):
+        W, U, b = leaves[3 * d: 3 * d + 3]
+        assert_close(grads[d]["dW"], W.grad, 1e-4, f"dW[{d}]")
+        assert_close(grads[d]["dU"], U.grad, 1e-4, f"dU[{d}]")
+        assert_close(grads[d]["db"], b.grad, 1e-4, f"db[{d}]")
+        if init:
+            assert_close(grads[d]["dh0"], il[d * nst].grad, 1e-4, f"dh0[{d}]")
+            if rt == "lstm":
+                assert_close(grads[d]["dc0"], il[d * nst + 1].grad, 1e-4, f"dc0[{d}]")
+
+
+@pytest.mark.parametrize("rt,H,B,T,D,pad", [("rnn", 13, 23, 11, 8, 3), ("lstm", 33, 34, 41, 2, 4), ("gru", 111, 55, 3, 99, 5)])
+def test_masked_padding_does_not_change_prefix(rt, H, B, T, D, pad):
+    """reference tests/models/test_las.py:21-44 (same parametrisation)."""
+    g = torch.Generator().manual_seed(H)
+    fwd, bwd = make_params(rt, D, H, g)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = torch.randn(B, T, generator=g) > 0.1
+    y, st = HipBiRNN(rt, x, mask, fwd, bwd).forward()
+    xp = torch.cat([x, torch.randn(B, pad, D, generator=g, dtype=torch.float64)], dim=1)
+    mp = torch.cat([mask, torch.zeros(B, pad, dtype=torch.bool)], dim=1)
+    yp, stp = HipBiRNN(rt, xp, mp, fwd, bwd).forward()
+    assert tuple(yp.shape) == (B, T + pad, 2 * H)
+    assert torch.equal(y, yp[:, :T])          # the reference asserts exact equality
+    assert torch.equal(st[0], stp[0])
+
+
+def test_invalid_rnn_type_raises_value_error():
+    from speech_recognition_amd import ops
+    with pytest.raises(ValueError, match="rnn_type: foo is invalid!"):
+        ops.rnn_geometry("foo", 8, [8])
