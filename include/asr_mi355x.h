@@ -73,6 +73,7 @@ typedef struct asr_gemm_desc {
   int trans_a, trans_b;        /* 0: A is [M,K] / B is [K,N];  1: A is [K,M] / B is [N,K]          */
   int M, N, K;
   int batch;                   /* z extent (>= 1)                                                   */
+  int split_k;                 /* > 1: partition K over that many workgroups (atomic accumulation)  */
   long lda, ldb, ldc;          /* row strides of the stored matrices, in elements                   */
   long stride_a, stride_b, stride_c, stride_a_scale; /* per-z strides; stride_c == 0 with batch > 1 = split-K (atomic) */
   float alpha;
@@ -85,6 +86,97 @@ typedef struct asr_gemm_desc {
   int c_rpg;
 } asr_gemm_desc;
 int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv2D, padding VALID, NHWC activations, HWIO kernel, linear (las.py:163-164 + 183-184,
+ * deepspeech2.py:47-50 + 57-59) and its two gradients, as implicit GEMMs on the MFMA.
+ * x [B,H,W,C], w [kh,kw,C,O], y [B,Ho,Wo,O] with Ho = (H-kh)/sh + 1, Wo = (W-kw)/sw + 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct asr_conv_desc {
+  int B, H, W, C;   /* input  */
+  int kh, kw, sh, sw, O;
+} asr_conv_desc;
+int asr_conv2d_out_dims(const asr_conv_desc* d, int* Ho, int* Wo);
+/* y = conv(x, w) + bias, then optional Keras Dropout (las.py:183-184): y *= mult(stream, flat index) */
+int asr_conv2d_fwd(const asr_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                   const uint32_t* drop_seed, uint32_t drop_stream, float drop_rate, void* stream);
+/* dw += im2col(x)^T dy   (atomic accumulation: dw must hold zeros or a running sum) */
+int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
+/* dx = full correlation of dy with w (overwrites dx) */
+int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, const float* w, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Memory-bound layer kernels
+ * ------------------------------------------------------------------------------------------ */
+int asr_fill_f32(float* p, long n, float value, void* stream);
+/* Listener._audio_mask (las.py:205-217) / Convolution._audio_mask (deepspeech2.py:68-78):
+ * out[b][j] = any(x[b, j*group : (j+1)*group, :] != 0.0); x [B,T,FC], out [B,Tout] uint8 */
+int asr_frame_mask(const float* x, int B, int T, int FC, int group, int Tout, uint8_t* out, void* stream);
+/* out[c] += sum_r A[r][c]  (bias gradients; atomic) */
+int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream);
+/* BatchNormalization(axis=-1) (+ fused ReLU) over x [M, C] (las.py:170,193; deepspeech2.py:112,118).
+ * training: biased batch statistics over all M rows, mean/rstd saved, moving stats updated with
+ * `momentum`; inference: moving statistics.  stats_ws: 2*C doubles of scratch. */
+int asr_bn_fwd(const float* x, int M, int C, long ld, const float* gamma, const float* beta, float eps, float momentum,
+               int relu, int training, float* y, long ldy, float* mean_out, float* rstd_out, float* moving_mean,
+               float* moving_var, double* stats_ws, void* stream);
+/* dx overwritten; dgamma/dbeta accumulated (+=).  y is the forward output (needed when relu). */
+int asr_bn_bwd(const float* x, const float* y, const float* dy, int M, int C, long ld, long ldy, long lddy,
+               const float* mean, const float* rstd, const float* gamma, int relu, float* dx, long lddx, float* dgamma,
+               float* dbeta, double* sums_ws, void* stream);
+
+/* Dropout sites addressed per row: element (r, k) uses RNG stream stream0 + stream_step * (r % period)
+ * and index (r / period) * idx_ld + idx_off + k; rate <= 0 disables the site. */
+typedef struct asr_rowdrop {
+  uint32_t stream0, stream_step;
+  int period;
+  long idx_ld;
+  int idx_off;
+  float rate;
+} asr_rowdrop;
+int asr_dropout_rows(const float* x, long ldx, float* y, long ldy, int R, int K, const uint32_t* seed, uint32_t stream0,
+                     uint32_t stream_step, int period, long idx_ld, int idx_off, float rate, void* stream);
+/* x[i] *= mult(stream_id, i) in place (gradient of a whole-tensor Keras Dropout) */
+int asr_dropout_flat(float* x, long n, const uint32_t* seed, uint32_t stream_id, float rate, void* stream);
+/* out[i] = mult(stream_id, i): the [B, D] table of a Keras RNN input dropout (las.py:94,102) */
+int asr_dropout_table(float* out, long n, const uint32_t* seed, uint32_t stream_id, float rate, void* stream);
+/* Embedding (las.py:258,278): backward == 0: x[r,:] = E[tok[r],:] * drop1 * drop2;
+ * backward != 0: dE[tok[r],:] += dx[r,:] * drop1 * drop2 (atomic).  R rows, Hd columns. */
+int asr_embedding(int backward, float* E_or_dE, const int32_t* tok, int R, int Hd, int V, float* x_or_dx, long ld,
+                  const uint32_t* seed, const asr_rowdrop* drop1, const asr_rowdrop* drop2, void* stream);
+/* out[r] = argmax_c x[r][c], lowest index on ties (tf.argmax, las.py:372) */
+int asr_argmax_rows(const float* x, long ld, int R, int N, int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder attention, one step (las.py:43-59 as called from las.py:282) with the key projections
+ * hoisted out of the step loop: Kq = (enc Wk + bk) Wq^T, s0 = (enc Wk + bk) bq.
+ * ------------------------------------------------------------------------------------------ */
+int asr_attn_step_fwd(const float* h, long ldh, const float* Kq, const float* s0, const uint8_t* mask, const float* enc, int B,
+                      int T, int Hd, int D, float* e, float* p, float* ctx, long ldctx, void* stream);
+int asr_attn_step_bwd(const float* dctx, long lddctx, const float* p, const float* Kq, const float* enc, int B, int T, int Hd,
+                      int D, float* dp, float* ds, float* dh, long lddh, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked sparse softmax cross-entropy + accuracy (measure.py:4-21, 45-69), forward and gradient in
+ * one pass.  logits [R, V] are overwritten with grad_scale * d(mean NLL)/d logits when write_grad.
+ * stats (3 floats, zeroed by the caller): [0] loss (mean NLL over kept tokens), [1] #correct, [2] #kept.
+ * ------------------------------------------------------------------------------------------ */
+int asr_softmax_xent(float* logits, long ld, const int32_t* labels, int R, int V, int ignore_index, float* stats, int write_grad,
+                     float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (run/train.py:159-168, Keras semantics) fused with LRScheduler (utils.py:11-35) over one flat
+ * parameter buffer.  `state` (device int32[4]): [0] iterations, [1] dropout seed.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct asr_lr_schedule {
+  float increasing_delta, decreasing_delta, max_learning_rate, min_learning_rate;
+  int warmup_steps, offset_steps;
+} asr_lr_schedule;
+int asr_lr_schedule_init(asr_lr_schedule* s, long total_steps, double max_learning_rate, double min_learning_rate,
+                         double warmup_rate, long warmup_steps, long offset_steps);
+int asr_adam_step(float* params, const float* grads, float* m, float* v, long n, const int32_t* state,
+                  const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int asr_advance_state(int32_t* state, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ class LogmelCfg(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [("trans_a", C.c_int), ("trans_b", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-                ("batch", C.c_int), ("lda", c_long), ("ldb", c_long), ("ldc", c_long), ("stride_a", c_long),
+                ("batch", C.c_int), ("split_k", C.c_int), ("lda", c_long), ("ldb", c_long), ("ldc", c_long), ("stride_a", c_long),
                 ("stride_b", c_long), ("stride_c", c_long), ("stride_a_scale", c_long), ("alpha", C.c_float),
                 ("accumulate", C.c_int), ("relu", C.c_int), ("bias", c_f32p), ("a_scale", c_f32p), ("a_rpg", C.c_int),
                 ("c_scale", c_f32p), ("c_rpg", C.c_int)]
@@ -77,9 +77,25 @@ class RnnSeqGrad(C.Structure):
                 ("dh0_ld", c_long * 2)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("sh", C.c_int), ("sw", C.c_int), ("O", C.c_int)]
+
+
+class RowDrop(C.Structure):
+    _fields_ = [("stream0", C.c_uint32), ("stream_step", C.c_uint32), ("period", C.c_int), ("idx_ld", c_long),
+                ("idx_off", C.c_int), ("rate", C.c_float)]
+
+
+class LrSchedule(C.Structure):
+    _fields_ = [("increasing_delta", C.c_float), ("decreasing_delta", C.c_float), ("max_learning_rate", C.c_float),
+                ("min_learning_rate", C.c_float), ("warmup_steps", C.c_int), ("offset_steps", C.c_int)]
+
+
 STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom,
            "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
-           "asr_rnn_seq_grad": RnnSeqGrad}
+           "asr_rnn_seq_grad": RnnSeqGrad, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
+           "asr_lr_schedule": LrSchedule}
 
 # symbol -> (restype, argtypes); every function declared in include/asr_mi355x.h
 _P = C.c_void_p
@@ -100,6 +116,32 @@ SIGNATURES = {
                                   C.c_int, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),
+    "asr_conv2d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "asr_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_uint32, C.c_float, _P]),
+    "asr_conv2d_bwd_filter": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "asr_conv2d_bwd_data": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "asr_fill_f32": (C.c_int, [_P, c_long, C.c_float, _P]),
+    "asr_frame_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "asr_colsum": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P]),
+    "asr_bn_fwd": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P, C.c_float, C.c_float, C.c_int, C.c_int, _P, c_long,
+                             _P, _P, _P, _P, _P, _P]),
+    "asr_bn_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, c_long, c_long, c_long, _P, _P, _P, C.c_int, _P, c_long, _P,
+                             _P, _P, _P]),
+    "asr_dropout_rows": (C.c_int, [_P, c_long, _P, c_long, C.c_int, C.c_int, _P, C.c_uint32, C.c_uint32, C.c_int,
+                                   c_long, C.c_int, C.c_float, _P]),
+    "asr_dropout_flat": (C.c_int, [_P, c_long, _P, C.c_uint32, C.c_float, _P]),
+    "asr_dropout_table": (C.c_int, [_P, c_long, _P, C.c_uint32, C.c_float, _P]),
+    "asr_embedding": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, c_long, _P, C.POINTER(RowDrop),
+                                C.POINTER(RowDrop), _P]),
+    "asr_argmax_rows": (C.c_int, [_P, c_long, C.c_int, C.c_int, _P, _P]),
+    "asr_attn_step_fwd": (C.c_int, [_P, c_long, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long, _P]),
+    "asr_attn_step_bwd": (C.c_int, [_P, c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long,
+                                    C.c_int, _P]),
+    "asr_softmax_xent": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
+    "asr_lr_schedule_init": (C.c_int, [C.POINTER(LrSchedule), c_long, C.c_double, C.c_double, C.c_double, c_long, c_long]),
+    "asr_adam_step": (C.c_int, [_P, _P, _P, _P, c_long, _P, C.POINTER(LrSchedule), C.c_float, C.c_float, C.c_float,
+                                C.c_float, _P]),
+    "asr_advance_state": (C.c_int, [_P, _P]),
 }
 
 _lib = None

@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
       const int lo = a.melrange[m], hi = a.melrange[a.nmel + m];
       float s = 0.f;
       for (int bin = lo; bin <= hi; ++bin) s = fmaf(P[frame * a.PLD + bin], a.melw[bin * a.nmel + m], s);
-      v = logf(s + a.eps);
+      // f32 add like tf.math.log(mel + eps), then a correctly rounded log (the reference's silence
+      // fixture pins log(1e-12f) to the last bit; the fast f32 log is 1 ulp off there)
+      const float se = s + a.eps;
+      v = (float)log((double)se);
       bool zero = false;
       for (int i = 0; i < a.sa_mF && i < FE_MAXBAND; ++i)
         zero |= (m >= bands[i] && m < bands[i] + bands[FE_MAXBAND + i]);

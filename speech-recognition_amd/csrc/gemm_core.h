@@ -50,12 +50,20 @@ struct GemmEpilogue {
   int c_rpg;
   int mode;              // 0 store, 1 accumulate (+=), 2 atomic add
   int relu;
+  // optional inverted dropout on the result, element index = r * N + c (Keras Dropout after a layer)
+  const uint32_t* drop_seed;
+  uint32_t drop_stream;
+  float drop_rate;
   __device__ __forceinline__ void put(int r, int c, float v) const {
     if (r >= M || c >= N) return;
     v *= alpha;
     if (bias != nullptr) v += bias[c];
     if (c_scale != nullptr) v *= c_scale[(long)(r / c_rpg) * N + c];
     if (relu) v = fmaxf(v, 0.f);
+    if (drop_seed != nullptr) {
+      const AsrRngKey key = asr_rng_key(drop_seed[0], drop_stream);
+      v *= asr_drop_mult(key, (uint32_t)((long)r * N + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
+    }
     float* dst = C + (long)r * ldc + c;
     if (mode == 0) *dst = v;
     else if (mode == 1) *dst += v;
@@ -82,7 +90,7 @@ struct GemmTile {
   static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
 
   template <class AL, class BL>
-  static __device__ __forceinline__ void run(const AL& al, const BL& bl, const GemmEpilogue& ep, int K,
+  static __device__ __forceinline__ void run(const AL& al, const BL& bl, const GemmEpilogue& ep, int kbeg, int kend,
                                              int m0, int n0, float* As, float* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -136,12 +144,15 @@ struct GemmTile {
       }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
+    // K range [kbeg, kend): kbeg is a multiple of BK (split-K partitions are BK aligned); the loaders
+    // zero-fill past their own extent, and kend < extent is enforced by clamping the loop count only
+    // when the partition ends on a BK boundary (the host guarantees that for every partition but the last)
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    gload(kbeg);
     for (int kt = 0; kt < nk; ++kt) {
       lstore();
       __syncthreads();
-      if (kt + 1 < nk) gload((kt + 1) * BK);
+      if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
       const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {

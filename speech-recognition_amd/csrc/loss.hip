@@ -1,0 +1,91 @@
+// Losses for gfx950.
+//  * masked sparse softmax cross-entropy + accuracy, forward and gradient in one pass over the logits
+//    (measure.py:4-21 SparseCategoricalCrossentropy, measure.py:45-69 SparseCategoricalAccuracy, and the
+//    Keras SUM_OVER_BATCH_SIZE mean over the kept tokens).
+//  * CTC (measure.py:24-42): see ctc kernels below.
+// HBM-bound: each logits row is read once into LDS, reduced with wave shuffles, and the gradient is
+// written once in place.
+#include "common.h"
+
+// stats layout (float): [0] sum of per-token NLL / n_valid (= the loss), [1] number of correct argmax, [2] n_valid
+// One workgroup per row r = (b, u).  Row cached in LDS when it fits (V <= 36864), otherwise re-read.
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void softmax_xent_kernel(float* logits, long ld, const int32_t* labels, int R, int V, int ignore_index,
+                                                           float* stats, int write_grad, float grad_scale) {
+  extern __shared__ float row[];
+  __shared__ float red[16];
+  __shared__ int redi[4];
+  __shared__ float redv[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float* x = logits + (long)r * ld;
+  // number of kept tokens (every block recomputes it: R ints, L2 resident)
+  float cnt = 0.f;
+  for (int i = tid; i < R; i += 256) cnt += (labels[i] != ignore_index) ? 1.f : 0.f;
+  cnt = block_sum(cnt, red);
+  const int y = labels[r];
+  const bool keep = (y != ignore_index);
+  if (!keep) {
+    if (write_grad)
+      for (int c = tid; c < V; c += 256) x[c] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  int am = 0x7fffffff;
+  for (int c = tid; c < V; c += 256) {
+    const float v = x[c];
+    if (IN_LDS) row[c] = v;
+    if (v > mx) { mx = v; am = c; }
+  }
+  // argmax with lowest-index tie break (tf.argmax) and the row max
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(am, o, 64);
+    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+  }
+  if (lane == 0) { redv[w] = mx; redi[w] = am; }
+  __syncthreads();
+  mx = redv[0]; am = redi[0];
+  for (int i = 1; i < 4; ++i)
+    if (redv[i] > mx || (redv[i] == mx && redi[i] < am)) { mx = redv[i]; am = redi[i]; }
+  float s = 0.f;
+  for (int c = tid; c < V; c += 256) s += expf((IN_LDS ? row[c] : x[c]) - mx);
+  s = block_sum(s, red);
+  const float lse = mx + logf(s);
+  const float inv_cnt = cnt > 0.f ? 1.f / cnt : 0.f;
+  if (tid == 0) {
+    const float xy = IN_LDS ? row[y] : x[y];
+    atomicAdd(&stats[0], (lse - xy) * inv_cnt);
+    atomicAdd(&stats[1], am == y ? 1.f : 0.f);
+    if (r == 0) stats[2] = cnt;
+  }
+  if (write_grad) {
+    const float g = grad_scale * inv_cnt;
+    for (int c = tid; c < V; c += 256) {
+      const float pz = expf((IN_LDS ? row[c] : x[c]) - lse);
+      x[c] = (pz - (c == y ? 1.f : 0.f)) * g;
+    }
+  }
+}
+
+// logits [R, V] (row stride ld) are overwritten by d loss / d logits when write_grad != 0.
+// stats (3 floats, device) must be zeroed by the caller before the call.
+extern "C" int asr_softmax_xent(float* logits, long ld, const int32_t* labels, int R, int V, int ignore_index, float* stats, int write_grad,
+                                float grad_scale, void* stream) {
+  ASR_CHECK(logits && labels && stats && R > 0 && V > 0 && ld >= V, ASR_ERR_ARG, "asr_softmax_xent: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = sizeof(float) * (size_t)V;
+  if (bytes <= 144 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(softmax_xent_kernel<true>, dim3((unsigned)R), dim3(256), bytes, st, logits, ld, labels, R, V, ignore_index, stats,
+                       write_grad, grad_scale);
+  } else {
+    hipLaunchKernelGGL(softmax_xent_kernel<false>, dim3((unsigned)R), dim3(256), 0, st, logits, ld, labels, R, V, ignore_index, stats, write_grad,
+                       grad_scale);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

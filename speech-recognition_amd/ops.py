@@ -101,7 +101,7 @@ def _mat(t, name):
 
 
 def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias=None, relu=False, a_scale=None,
-         a_rpg=0, c_scale=None, c_rpg=0):
+         a_rpg=0, c_scale=None, c_rpg=0, split_k=1):
     """c (+)= alpha * op(a) @ op(b) (+ bias).  2-D operands, or 3-D with a leading batch axis; a 2-D `c`
     with 3-D a/b means split-K over the batch axis (atomic accumulation, requires accumulate)."""
     _mat(a, "a"), _mat(b, "b"), _mat(c, "c")
@@ -115,6 +115,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     d = _lib.GemmDesc()
     d.trans_a, d.trans_b = int(trans_a), int(trans_b)
     d.M, d.N, d.K, d.batch = am, bn, ak, batch
+    d.split_k = int(split_k)
     d.lda, d.ldb, d.ldc = a.stride(-2), b.stride(-2), c.stride(-2)
     d.stride_a = a.stride(0) if a.dim() == 3 else 0
     d.stride_b = b.stride(0) if b.dim() == 3 else 0
@@ -227,3 +228,180 @@ def slab_reduce(slab, geom, B, col0, ncols, out, add=None, accumulate=False):
     check(lib().asr_slab_reduce(_p(slab), geom.Q, Bpad * geom.slab_ld, geom.slab_ld, col0, ncols, B, _p(add),
                                 add.stride(0) if add is not None else 0, _p(out), out.stride(0), int(accumulate), _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------------------- cells (decoder steps)
+def rnn_cell_fwd(rnn_type, B, H, steps, seed=None):
+    """steps: list (1 or 2 directions) of _lib.RnnStepFwd."""
+    arr = (_lib.RnnStepFwd * len(steps))(*steps)
+    check(lib().asr_rnn_cell_fwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _p(seed), _stream()))
+
+
+def rnn_cell_bwd(rnn_type, B, H, steps):
+    arr = (_lib.RnnStepBwd * len(steps))(*steps)
+    check(lib().asr_rnn_cell_bwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _stream()))
+
+
+# ----------------------------------------------------------------------------------------- conv
+def conv_desc(x_shape, w_shape, strides):
+    B, H, W, Cc = x_shape
+    kh, kw, Ci, O = w_shape
+    if Ci != Cc:
+        raise ValueError(f"conv2d: input channels {Cc} != kernel channels {Ci}")
+    sh, sw = (strides, strides) if isinstance(strides, int) else strides
+    return _lib.ConvDesc(B, H, W, Cc, kh, kw, sh, sw, O)
+
+
+def conv_out_dims(d):
+    ho, wo = C.c_int(), C.c_int()
+    check(lib().asr_conv2d_out_dims(C.byref(d), C.byref(ho), C.byref(wo)))
+    return ho.value, wo.value
+
+
+def conv2d_fwd(x, w, bias, strides, y=None, seed=None, drop_stream=0, drop_rate=0.0):
+    _dev(x, name="x"), _dev(w, name="w")
+    d = conv_desc(x.shape, w.shape, strides)
+    Ho, Wo = conv_out_dims(d)
+    if y is None:
+        y = torch.empty(d.B, Ho, Wo, d.O, device=x.device, dtype=torch.float32)
+    assert x.is_contiguous() and w.is_contiguous() and y.is_contiguous()
+    check(lib().asr_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(seed) if drop_rate > 0 else None, drop_stream,
+                               float(drop_rate), _stream()))
+    return y
+
+
+def conv2d_bwd_filter(x, dy, dw, strides):
+    d = conv_desc(x.shape, dw.shape, strides)
+    assert x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous()
+    check(lib().asr_conv2d_bwd_filter(C.byref(d), _p(x), _p(dy), _p(dw), _stream()))
+    return dw
+
+
+def conv2d_bwd_data(dy, w, dx, strides):
+    d = conv_desc(dx.shape, w.shape, strides)
+    assert dx.is_contiguous() and dy.is_contiguous() and w.is_contiguous()
+    check(lib().asr_conv2d_bwd_data(C.byref(d), _p(dy), _p(w), _p(dx), _stream()))
+    return dx
+
+
+# ----------------------------------------------------------------------------------------- memory-bound layers
+def fill(t, value=0.0):
+    assert t.is_contiguous()
+    _dev(t, name="t")
+    check(lib().asr_fill_f32(_p(t), t.numel(), float(value), _stream()))
+    return t
+
+
+def frame_mask(x, group, Tout, out=None):
+    """x [B,T,...] -> uint8 [B,Tout]; out[b,j] = any(x[b, j*group:(j+1)*group] != 0)."""
+    _dev(x, name="x")
+    B, T = x.shape[:2]
+    FC = x.numel() // (B * T)
+    if out is None:
+        out = torch.empty(B, Tout, device=x.device, dtype=torch.uint8)
+    assert x.is_contiguous()
+    check(lib().asr_frame_mask(_p(x), B, T, FC, group, Tout, _p(out), _stream()))
+    return out
+
+
+def colsum(a, out):
+    """out[c] += sum_r a[r, c] (a 2-D, unit inner stride)."""
+    check(lib().asr_colsum(_p(a), a.shape[0], a.shape[1], a.stride(0), _p(out), _stream()))
+    return out
+
+
+def bn_fwd(x, gamma, beta, y, mean, rstd, moving_mean, moving_var, ws, *, relu, training, eps=1e-3, momentum=0.99):
+    M, Cc = x.shape
+    check(lib().asr_bn_fwd(_p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), eps, momentum, int(relu), int(training), _p(y),
+                           y.stride(0), _p(mean), _p(rstd), _p(moving_mean), _p(moving_var), _p(ws), _stream()))
+    return y
+
+
+def bn_bwd(x, y, dy, mean, rstd, gamma, dx, dgamma, dbeta, ws, *, relu):
+    M, Cc = x.shape
+    check(lib().asr_bn_bwd(_p(x), _p(y), _p(dy), M, Cc, x.stride(0), y.stride(0) if y is not None else 0, dy.stride(0), _p(mean),
+                           _p(rstd), _p(gamma), int(relu), _p(dx), dx.stride(0), _p(dgamma), _p(dbeta), _p(ws), _stream()))
+    return dx
+
+
+def rowdrop(stream0=0, stream_step=0, period=1, idx_ld=0, idx_off=0, rate=0.0):
+    return _lib.RowDrop(stream0, stream_step, period, idx_ld, idx_off, rate)
+
+
+def dropout_rows(x, y, seed, rd):
+    R, K = x.shape
+    check(lib().asr_dropout_rows(_p(x), x.stride(0), _p(y), y.stride(0), R, K, _p(seed), rd.stream0, rd.stream_step, rd.period,
+                                 rd.idx_ld, rd.idx_off, rd.rate, _stream()))
+    return y
+
+
+def dropout_flat(x, seed, stream_id, rate):
+    assert x.is_contiguous()
+    check(lib().asr_dropout_flat(_p(x), x.numel(), _p(seed), stream_id, float(rate), _stream()))
+    return x
+
+
+def dropout_table(out, seed, stream_id, rate):
+    assert out.is_contiguous()
+    check(lib().asr_dropout_table(_p(out), out.numel(), _p(seed), stream_id, float(rate), _stream()))
+    return out
+
+
+def embedding_fwd(E, tok, out, seed=None, drop1=None, drop2=None):
+    R = tok.numel()
+    V, Hd = E.shape
+    check(lib().asr_embedding(0, _p(E), _p(tok), R, Hd, V, _p(out), out.stride(-2), _p(seed),
+                              C.byref(drop1) if drop1 else None, C.byref(drop2) if drop2 else None, _stream()))
+    return out
+
+
+def embedding_bwd(dE, tok, dx, seed=None, drop1=None, drop2=None):
+    R = tok.numel()
+    V, Hd = dE.shape
+    check(lib().asr_embedding(1, _p(dE), _p(tok), R, Hd, V, _p(dx), dx.stride(-2), _p(seed),
+                              C.byref(drop1) if drop1 else None, C.byref(drop2) if drop2 else None, _stream()))
+    return dE
+
+
+def argmax_rows(x, out):
+    check(lib().asr_argmax_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------------------- attention / loss / optimizer
+def attn_step_fwd(h, Kq, s0, mask, enc, e, p, ctx):
+    B, T, Hd = Kq.shape
+    D = enc.shape[2]
+    check(lib().asr_attn_step_fwd(_p(h), h.stride(0), _p(Kq), _p(s0), _p(mask), _p(enc), B, T, Hd, D, _p(e), _p(p), _p(ctx),
+                                  ctx.stride(0), _stream()))
+
+
+def attn_step_bwd(dctx, p, Kq, enc, dp, ds, dh, accumulate):
+    B, T, Hd = Kq.shape
+    D = enc.shape[2]
+    check(lib().asr_attn_step_bwd(_p(dctx), dctx.stride(0), _p(p), _p(Kq), _p(enc), B, T, Hd, D, _p(dp), _p(ds), _p(dh),
+                                  dh.stride(0), int(accumulate), _stream()))
+
+
+def softmax_xent(logits, labels, stats, ignore_index=0, write_grad=True, grad_scale=1.0):
+    """logits [R, V] overwritten with the gradient; stats (3 floats) must be pre-zeroed."""
+    R, V = logits.shape
+    _dev(labels, torch.int32, "labels")
+    check(lib().asr_softmax_xent(_p(logits), logits.stride(0), _p(labels), R, V, ignore_index, _p(stats), int(write_grad),
+                                 float(grad_scale), _stream()))
+
+
+def lr_schedule(total_steps, max_learning_rate, min_learning_rate, warmup_rate=0.0, warmup_steps=0, offset_steps=0):
+    s = _lib.LrSchedule()
+    check(lib().asr_lr_schedule_init(C.byref(s), int(total_steps), float(max_learning_rate), float(min_learning_rate),
+                                     float(warmup_rate), int(warmup_steps or 0), int(offset_steps or 0)))
+    return s
+
+
+def adam_step(params, grads, m, v, state, sched, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    check(lib().asr_adam_step(_p(params), _p(grads), _p(m), _p(v), params.numel(), _p(state), C.byref(sched), beta1, beta2,
+                              eps, grad_scale, _stream()))
+
+
+def advance_state(state):
+    check(lib().asr_advance_state(_p(state), _stream()))
