@@ -125,8 +125,9 @@ int asr_bn_bwd(const float* x, const float* y, const float* dy, int M, int C, lo
                const float* mean, const float* rstd, const float* gamma, int relu, float* dx, long lddx, float* dgamma,
                float* dbeta, double* sums_ws, void* stream);
 
-/* Dropout sites addressed per row: element (r, k) uses RNG stream stream0 + stream_step * (r % period)
- * and index (r / period) * idx_ld + idx_off + k; rate <= 0 disables the site. */
+/* Dropout sites addressed per row.  Rows are (batch b, step i) pairs: period > 0 means batch-major
+ * rows (r = b*period + i), period < 0 step-major rows (r = i*|period| + b).  Element (r, k) uses RNG
+ * stream stream0 + stream_step * i and index b * idx_ld + idx_off + k; rate <= 0 disables the site. */
 typedef struct asr_rowdrop {
   uint32_t stream0, stream_step;
   int period;
@@ -144,6 +145,8 @@ int asr_dropout_table(float* out, long n, const uint32_t* seed, uint32_t stream_
  * backward != 0: dE[tok[r],:] += dx[r,:] * drop1 * drop2 (atomic).  R rows, Hd columns. */
 int asr_embedding(int backward, float* E_or_dE, const int32_t* tok, int R, int Hd, int V, float* x_or_dx, long ld,
                   const uint32_t* seed, const asr_rowdrop* drop1, const asr_rowdrop* drop2, void* stream);
+/* out[i*out_stride] = (tok[i] != pad)  (decoder step mask, las.py:276) */
+int asr_token_mask(const int32_t* tok, long n, int pad, uint8_t* out, long out_stride, void* stream);
 /* out[r] = argmax_c x[r][c], lowest index on ties (tf.argmax, las.py:372) */
 int asr_argmax_rows(const float* x, long ld, int R, int N, int32_t* out, void* stream);
 
@@ -241,6 +244,8 @@ typedef struct asr_rnn_step_bwd {
   /* d loss / d (emitted output y)         = sum_q slabB[q][b][colB + j] + addB[b][j]               */
   const float* slabB; int QB; long slabB_qstride, slabB_ld; int colB;
   const float* addB; long addB_ld;
+  float dropB_rate; uint32_t dropB_stream; long dropB_ld; int dropB_off; /* > 0: the slabB sum is the gradient of a dropped-out
+                                               input: multiply by mult(stream, b*dropB_ld + dropB_off + j)                  */
   float* dc; long dc_ld;                    /* LSTM cell-state gradient, updated in place          */
   float* dy_carry; long dy_carry_ld;        /* pending output gradient across masked steps or NULL */
   const uint8_t* mask; long mask_ld;
@@ -252,11 +257,13 @@ typedef struct asr_rnn_step_bwd {
   float* slab_out; long slab_out_qstride, slab_out_ld; /* out: [Q][Bpad][16 NT] partial input gradients or NULL */
   int hcol;                                 /* first packed column of the recurrent segment        */
 } asr_rnn_step_bwd;
-int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, void* stream);
+int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream);
 
-/* out[b][c] (+)= sum_q slab[q][b][col0 + c] (+ add[b][c]) */
+/* out[b][c] (+)= (sum_q slab[q][b][col0 + c]) * drop (+ add[b][c]);
+ * drop = mult(drop_stream, b*drop_ld + drop_off + c) when drop_rate > 0 (gradient of a dropped-out cell input) */
 int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
-                    long add_ld, float* out, long out_ld, int accumulate, void* stream);
+                    long add_ld, float* out, long out_ld, int accumulate, const uint32_t* seed, uint32_t drop_stream,
+                    float drop_rate, long drop_ld, int drop_off, void* stream);
 
 /* A whole (Bi)RNN layer over time.  Tensors are batch-major: pre [B,T,G*H] (input projection incl.
  * bias), hseq/cseq [B,T,H] (states after each step, time order), y [B,T,y_ld] with direction d

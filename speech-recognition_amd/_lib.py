@@ -55,6 +55,7 @@ class RnnStepBwd(C.Structure):
                 ("addA", c_f32p), ("addA_ld", c_long),
                 ("slabB", c_f32p), ("QB", C.c_int), ("slabB_qstride", c_long), ("slabB_ld", c_long), ("colB", C.c_int),
                 ("addB", c_f32p), ("addB_ld", c_long),
+                ("dropB_rate", C.c_float), ("dropB_stream", C.c_uint32), ("dropB_ld", c_long), ("dropB_off", C.c_int),
                 ("dc", c_f32p), ("dc_ld", c_long), ("dy_carry", c_f32p), ("dy_carry_ld", c_long),
                 ("mask", c_f32p), ("mask_ld", c_long), ("saved", c_f32p), ("saved_ld", c_long),
                 ("h_prev", c_f32p), ("h_prev_ld", c_long), ("c_prev", c_f32p), ("c_prev_ld", c_long),
@@ -111,9 +112,10 @@ SIGNATURES = {
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), _P, _P, _P]),
     "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
-    "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P]),
+    "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
     "asr_slab_reduce": (C.c_int, [_P, C.c_int, c_long, c_long, C.c_int, C.c_int, C.c_int, _P, c_long, _P, c_long,
-                                  C.c_int, _P]),
+                                  C.c_int, _P, C.c_uint32, C.c_float, c_long, C.c_int, _P]),
+    "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),
     "asr_conv2d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

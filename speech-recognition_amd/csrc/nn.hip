@@ -207,8 +207,11 @@ extern "C" int asr_bn_bwd(const float* x, const float* y, const float* dy, int M
 struct RowDrop { uint32_t stream0, stream_step; int period; long idx_ld; int idx_off; float rate; };
 __device__ __forceinline__ float rowdrop_mult(const RowDrop& d, uint32_t seed, int r, int k) {
   if (d.rate <= 0.f) return 1.f;
-  const AsrRngKey key = asr_rng_key(seed, d.stream0 + d.stream_step * (uint32_t)(r % d.period));
-  return asr_drop_mult(key, (uint32_t)((long)(r / d.period) * d.idx_ld + d.idx_off + k), asr_drop_threshold(d.rate), 1.f / (1.f - d.rate));
+  // period > 0: rows are batch-major (r = b * period + step); period < 0: step-major (r = step * |period| + b)
+  const int step = d.period > 0 ? r % d.period : r / (-d.period);
+  const int b = d.period > 0 ? r / d.period : r % (-d.period);
+  const AsrRngKey key = asr_rng_key(seed, d.stream0 + d.stream_step * (uint32_t)step);
+  return asr_drop_mult(key, (uint32_t)((long)b * d.idx_ld + d.idx_off + k), asr_drop_threshold(d.rate), 1.f / (1.f - d.rate));
 }
 __global__ void dropout_rows_kernel(const float* x, long ldx, float* y, long ldy, int R, int K, const uint32_t* seed, RowDrop d) {
   const uint32_t sd = seed[0];
@@ -220,7 +223,7 @@ __global__ void dropout_rows_kernel(const float* x, long ldx, float* y, long ldy
 }
 extern "C" int asr_dropout_rows(const float* x, long ldx, float* y, long ldy, int R, int K, const uint32_t* seed, uint32_t stream0,
                                 uint32_t stream_step, int period, long idx_ld, int idx_off, float rate, void* stream) {
-  ASR_CHECK(x && y && seed && R > 0 && K > 0 && period > 0, ASR_ERR_ARG, "asr_dropout_rows: bad argument");
+  ASR_CHECK(x && y && seed && R > 0 && K > 0 && period != 0, ASR_ERR_ARG, "asr_dropout_rows: bad argument");
   RowDrop d{stream0, stream_step, period, idx_ld, idx_off, rate};
   const long n = (long)R * K;
   hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)min((long)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
@@ -300,7 +303,7 @@ extern "C" int asr_embedding(int backward, float* E_or_dE, const int32_t* tok, i
   RowDrop d1{0, 0, 1, 0, 0, 0.f}, d2{0, 0, 1, 0, 0, 0.f};
   if (drop1) d1 = RowDrop{drop1->stream0, drop1->stream_step, drop1->period, drop1->idx_ld, drop1->idx_off, drop1->rate};
   if (drop2) d2 = RowDrop{drop2->stream0, drop2->stream_step, drop2->period, drop2->idx_ld, drop2->idx_off, drop2->rate};
-  ASR_CHECK(d1.period > 0 && d2.period > 0, ASR_ERR_ARG, "asr_embedding: dropout period must be > 0");
+  ASR_CHECK(d1.period != 0 && d2.period != 0, ASR_ERR_ARG, "asr_embedding: dropout period must be != 0");
   const bool any = (d1.rate > 0.f || d2.rate > 0.f);
   ASR_CHECK(!(any && !seed), ASR_ERR_ARG, "asr_embedding: dropout needs a device seed");
   dim3 grid((unsigned)((R + 3) / 4));
@@ -341,6 +344,19 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, long l
 extern "C" int asr_argmax_rows(const float* x, long ld, int R, int N, int32_t* out, void* stream) {
   ASR_CHECK(x && out && R > 0 && N > 0, ASR_ERR_ARG, "asr_argmax_rows: bad argument");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ld, R, N, out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+// out[i * out_stride] = tok[i] != pad  (decoder step mask, las.py:276)
+__global__ void token_mask_kernel(const int32_t* tok, long n, int pad, uint8_t* out, long out_stride) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i * out_stride] = tok[i] != pad ? 1 : 0;
+}
+extern "C" int asr_token_mask(const int32_t* tok, long n, int pad, uint8_t* out, long out_stride, void* stream) {
+  ASR_CHECK(tok && out && n > 0 && out_stride > 0, ASR_ERR_ARG, "asr_token_mask: bad argument");
+  hipLaunchKernelGGL(token_mask_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tok, n, pad, out,
+                     out_stride);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -196,6 +196,7 @@ struct BwdDir {
   // gradient wrt the emitted output y:           sum_q slabB[q][b][colB + j]  +  addB[b][j]
   const float* slabB; int QB; long slabB_qstride; long slabB_ld; int colB;
   const float* addB; long addB_ld;
+  float dropB_rate; uint32_t dropB_stream; long dropB_ld; int dropB_off;
   float* dc; long dc_ld;               // cell-state gradient, updated in place (LSTM)
   float* dy_carry; long dy_carry_ld;   // pending output gradient of masked steps (sequence use), may be null
   const uint8_t* mask; long mask_ld;
@@ -207,7 +208,7 @@ struct BwdDir {
   float* slab_out; long slab_out_qstride; long slab_out_ld;  // [Q][Bpad][NT*16]
   int hcol;                // first packed column of the recurrent segment
 };
-struct BwdArgs { BwdDir d[2]; int B, H; };
+struct BwdArgs { BwdDir d[2]; int B, H; const uint32_t* seed; };
 
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
@@ -236,6 +237,10 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
   red[wave][lane] = sb;
   __syncthreads();
   float dy = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (d.dropB_rate > 0.f && live) {
+    const AsrRngKey key = asr_rng_key(a.seed[0], d.dropB_stream);
+    dy *= asr_drop_mult(key, (uint32_t)((long)b * d.dropB_ld + d.dropB_off + j), asr_drop_threshold(d.dropB_rate), 1.f / (1.f - d.dropB_rate));
+  }
 
   // 2. gate gradients (wave 0)
   if (wave == 0) {
@@ -314,12 +319,17 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
 
 // sum of slabs: out[b][c] (+)= sum_q slab[q][b][col0 + c] (+ add[b][c])
 __global__ void slab_reduce_kernel(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B,
-                                   const float* add, long add_ld, float* out, long out_ld, int accumulate) {
+                                   const float* add, long add_ld, float* out, long out_ld, int accumulate,
+                                   const uint32_t* seed, uint32_t drop_stream, float drop_rate, long drop_ld, int drop_off) {
   const long n = (long)B * ncols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int b = (int)(i / ncols), c = (int)(i % ncols);
     float s = 0.f;
     for (int q = 0; q < Q; ++q) s += slab[(long)q * qstride + (long)b * ld + col0 + c];
+    if (drop_rate > 0.f) {
+      const AsrRngKey key = asr_rng_key(seed[0], drop_stream);
+      s *= asr_drop_mult(key, (uint32_t)((long)b * drop_ld + drop_off + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
+    }
     if (add) s += add[(long)b * add_ld + c];
     float* o = out + (long)b * out_ld + c;
     *o = accumulate ? *o + s : s;
@@ -458,6 +468,7 @@ static void fill_bwd_dir(BwdDir* d, const asr_rnn_step_bwd* s) {
   d->addA = s->addA; d->addA_ld = s->addA_ld;
   d->slabB = s->slabB; d->QB = s->QB; d->slabB_qstride = s->slabB_qstride; d->slabB_ld = s->slabB_ld; d->colB = s->colB;
   d->addB = s->addB; d->addB_ld = s->addB_ld;
+  d->dropB_rate = s->dropB_rate; d->dropB_stream = s->dropB_stream; d->dropB_ld = s->dropB_ld; d->dropB_off = s->dropB_off;
   d->dc = s->dc; d->dc_ld = s->dc_ld; d->dy_carry = s->dy_carry; d->dy_carry_ld = s->dy_carry_ld;
   d->mask = s->mask; d->mask_ld = s->mask_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
   d->h_prev = s->h_prev; d->h_prev_ld = s->h_prev_ld; d->c_prev = s->c_prev; d->c_prev_ld = s->c_prev_ld;
@@ -474,14 +485,15 @@ static int launch_bwd(int rnn_type, const BwdArgs& a, int ndir, hipStream_t st) 
   return ASR_OK;
 }
 
-extern "C" int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, void* stream) {
+extern "C" int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream) {
   ASR_CHECK(steps, ASR_ERR_ARG, "asr_rnn_cell_bwd: null argument");
   ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
   ASR_CHECK(B > 0 && H > 0 && (ndir == 1 || ndir == 2), ASR_ERR_SHAPE, "asr_rnn_cell_bwd: B %d H %d ndir %d", B, H, ndir);
   BwdArgs a{};
-  a.B = B; a.H = H;
+  a.B = B; a.H = H; a.seed = seed;
   for (int i = 0; i < ndir; ++i) {
     ASR_CHECK(steps[i].saved && steps[i].dslots, ASR_ERR_ARG, "asr_rnn_cell_bwd: saved/dslots missing");
+    ASR_CHECK(!(steps[i].dropB_rate > 0.f && !seed), ASR_ERR_ARG, "asr_rnn_cell_bwd: dropout needs a device seed");
     ASR_CHECK(rnn_type != CELL_LSTM || (steps[i].dc && steps[i].c_out), ASR_ERR_ARG, "asr_rnn_cell_bwd: LSTM needs dc and c_out");
     ASR_CHECK(!steps[i].slab_out || steps[i].Wpb, ASR_ERR_ARG, "asr_rnn_cell_bwd: slab_out needs Wpb");
     fill_bwd_dir(&a.d[i], &steps[i]);
@@ -512,7 +524,7 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
   hipStream_t st = (hipStream_t)stream;
   for (int step = T - 1; step >= 0; --step) {
     BwdArgs a{};
-    a.B = B; a.H = H;
+    a.B = B; a.H = H; a.seed = nullptr;
     for (int d = 0; d < s->ndir; ++d) {
       const bool rev = s->reverse[d] != 0;
       const int t = rev ? T - 1 - step : step;
@@ -553,7 +565,8 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
       const float* slab0 = gs->slab[d];  // step 0 -> parity 0
       const long n = (long)B * H;
       hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, st, slab0, g.Q,
-                         qstride, (long)g.slab_ld, 0, H, B, (const float*)nullptr, 0L, gs->dh0[d], gs->dh0_ld[d], 0);
+                         qstride, (long)g.slab_ld, 0, H, B, (const float*)nullptr, 0L, gs->dh0[d], gs->dh0_ld[d], 0,
+                         (const uint32_t*)nullptr, 0u, 0.f, 0L, 0);
     }
   }
   ASR_LAUNCH_CHECK();
@@ -561,11 +574,13 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
 }
 
 extern "C" int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
-                               long add_ld, float* out, long out_ld, int accumulate, void* stream) {
+                               long add_ld, float* out, long out_ld, int accumulate, const uint32_t* seed, uint32_t drop_stream,
+                               float drop_rate, long drop_ld, int drop_off, void* stream) {
   ASR_CHECK(slab && out && Q > 0 && B > 0 && ncols > 0, ASR_ERR_ARG, "asr_slab_reduce: bad argument");
+  ASR_CHECK(!(drop_rate > 0.f && !seed), ASR_ERR_ARG, "asr_slab_reduce: dropout needs a device seed");
   const long n = (long)B * ncols;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab,
-                     Q, qstride, ld, col0, ncols, B, add, add_ld, out, out_ld, accumulate);
+                     Q, qstride, ld, col0, ncols, B, add, add_ld, out, out_ld, accumulate, seed, drop_stream, drop_rate, drop_ld, drop_off);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

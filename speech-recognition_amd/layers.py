@@ -1,0 +1,189 @@
+"""Host-side building blocks shared by the LAS and DeepSpeech2 models: Dense / BiRNN layers with
+explicit forward and backward passes that only launch kernels of libasr_mi355x.so.
+
+There is no autograd here on purpose: every gradient is a hand-written kernel (or the MFMA GEMM)
+writing straight into the flat gradient buffer, in an order the data-parallel step can overlap with
+communication.  Buffers are allocated once per shape so that a whole training step can be captured
+in a hipGraph.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from . import rng as R
+
+NG = {"lstm": 4, "gru": 3, "rnn": 1}   # gates in the Keras kernel layout
+NS = {"lstm": 4, "gru": 4, "rnn": 1}   # columns saved per unit by the cell kernels ("slots")
+
+
+def auto_split_k(M, N, K):
+    """K partitions for a weight-gradient GEMM (tiny M x N, huge K) so that ~1k workgroups run."""
+    tiles = math.ceil(M / 128) * math.ceil(N / 128) if M > 64 and N > 64 else math.ceil(M / 64) * math.ceil(N / 64)
+    s = max(1, min(768 // max(tiles, 1), K // 128))
+    return max(1, s)
+
+
+def dense_fwd(x2d, W, b, out, relu=False, a_scale=None, a_rpg=0):
+    return ops.gemm(x2d, W, out, bias=b, relu=relu, a_scale=a_scale, a_rpg=a_rpg)
+
+
+def dense_bwd(x2d, W, dy2d, gW, gb, dx2d=None, dx_accumulate=False, a_scale=None, a_rpg=0, c_scale=None, c_rpg=0):
+    """gW += x^T dy ; gb += colsum(dy) ; dx (+)= dy W^T."""
+    Kd = x2d.shape[0]
+    ops.gemm(x2d, dy2d, gW, trans_a=True, accumulate=1, split_k=auto_split_k(gW.shape[0], gW.shape[1], Kd), a_scale=a_scale,
+             a_rpg=a_rpg)
+    if gb is not None:
+        ops.colsum(dy2d, gb)
+    if dx2d is not None:
+        ops.gemm(dy2d, W, dx2d, trans_b=True, accumulate=1 if dx_accumulate else 0, c_scale=c_scale, c_rpg=c_rpg)
+
+
+def slot_cols(rnn_type, H, which):
+    """Column ranges of the saved/dslots buffer [.., NS*H]: 'input' part (multiplies W) and 'rec' part
+    (multiplies U), each as list of (src_col0, dst_col0, ncols) into the Keras [G*H] layout."""
+    if rnn_type == "gru":
+        if which == "input":
+            return [(0, 0, 3 * H)]
+        return [(0, 0, 2 * H), (3 * H, 2 * H, H)]
+    n = NG[rnn_type] * H
+    return [(0, 0, n)]
+
+
+def cell_param_grads(rnn_type, H, x2d, hprev2d, ds2d, gW, gU, gb, a_scale=None, a_rpg=0):
+    """Weight gradients of one cell from the gate-sum gradients ds2d [R, NS*H] (R = rows in time/batch).
+    x2d [R, Din] (None = skip gW), hprev2d [R, H] (None = skip gU)."""
+    Rr = ds2d.shape[0]
+    for s0, d0, n in slot_cols(rnn_type, H, "input"):
+        dsv = ds2d[:, s0:s0 + n]
+        if x2d is not None:
+            ops.gemm(x2d, dsv, gW[:, d0:d0 + n], trans_a=True, accumulate=1, split_k=auto_split_k(gW.shape[0], n, Rr),
+                     a_scale=a_scale, a_rpg=a_rpg)
+        if gb is not None:
+            ops.colsum(dsv, (gb[0] if rnn_type == "gru" else gb)[d0:d0 + n])
+    for s0, d0, n in slot_cols(rnn_type, H, "rec"):
+        dsv = ds2d[:, s0:s0 + n]
+        if hprev2d is not None:
+            ops.gemm(hprev2d, dsv, gU[:, d0:d0 + n], trans_a=True, accumulate=1, split_k=auto_split_k(H, n, Rr))
+        if rnn_type == "gru" and gb is not None:
+            ops.colsum(dsv, gb[1][d0:d0 + n])
+
+
+def cell_input_grad(rnn_type, H, ds2d, W, dx2d, accumulate=False, c_scale=None, c_rpg=0):
+    """dx (+)= ds[:, input slots] W^T (optionally times a dropout table)."""
+    (s0, d0, n), = slot_cols(rnn_type, H, "input")
+    ops.gemm(ds2d[:, s0:s0 + n], W[:, d0:d0 + n], dx2d, trans_b=True, accumulate=1 if accumulate else 0, c_scale=c_scale, c_rpg=c_rpg)
+
+
+class BiRNN:
+    """BiRNN of las.py:62-126 on the step kernels: forward + backward LSTM/GRU/SimpleRNN over
+    x [B,T,Din] with a frame mask, chained initial states and Keras input dropout."""
+
+    def __init__(self, store, prefix, rnn_type, Din, H, dropout, stream_in, device="cuda"):
+        ops.rnn_type_id(rnn_type)
+        self.store, self.prefix, self.rt, self.Din, self.H = store, prefix, rnn_type, Din, H
+        self.dropout, self.stream_in = float(dropout), stream_in
+        self.cells = [ops.PackedCell(rnn_type, H, [H], device) for _ in range(2)]
+        self.names = [prefix + d + "/cell/" for d in ("forward_rnn", "backward_rnn")]
+
+    @staticmethod
+    def param_shapes(prefix, rnn_type, Din, H):
+        g = NG[rnn_type]
+        s = {}
+        for d in ("forward_rnn", "backward_rnn"):
+            s[f"{prefix}{d}/cell/kernel"] = (Din, g * H)
+            s[f"{prefix}{d}/cell/recurrent_kernel"] = (H, g * H)
+            s[f"{prefix}{d}/cell/bias"] = (2, g * H) if rnn_type == "gru" else (g * H,)
+        return s
+
+    def pack(self):
+        for d in range(2):
+            self.cells[d].pack([(self.store.p[self.names[d] + "recurrent_kernel"], True)])
+
+    def alloc(self, B, T, device="cuda"):
+        H, rt = self.H, self.rt
+        f = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
+        geom = self.cells[0].geom
+        buf = dict(B=B, T=T, y=f(B, T, 2 * H), dirs=[])
+        for d in range(2):
+            dd = dict(pre=f(B, T, NG[rt] * H), hseq=f(B, T, H), mtab=f(B, self.Din), slab=f(2 * ops.slab_floats(geom, B)),
+                      dy_carry=f(B, H), dh0=f(B, H), reverse=(d == 1), cell=self.cells[d])
+            dd["saved"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
+            if rt == "lstm":
+                dd["cseq"] = f(B, T, H)
+            buf["dirs"].append(dd)
+        return buf
+
+    def final_states(self, buf):
+        """[fh, (fc), bh, (bc)] as strided [B,H] views (las.py:126 order)."""
+        T, out = buf["T"], []
+        for dd in buf["dirs"]:
+            tl = 0 if dd["reverse"] else T - 1
+            out.append(dd["hseq"][:, tl])
+            if self.rt == "lstm":
+                out.append(dd["cseq"][:, tl])
+        return out
+
+    def forward(self, buf, x3d, mask, init_states, training, seed):
+        B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
+        nst = 2 if rt == "lstm" else 1
+        x2d = x3d.reshape(B * T, self.Din)
+        drop = training and self.dropout > 0
+        for d, dd in enumerate(buf["dirs"]):
+            p = self.store.p
+            W, b = p[self.names[d] + "kernel"], p[self.names[d] + "bias"]
+            if drop:
+                ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
+            ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=(b[0] if rt == "gru" else b), a_scale=dd["mtab"] if drop else None, a_rpg=T)
+            dd["bias_rec"] = b[1] if rt == "gru" else None
+            if init_states is not None:
+                st = init_states[d * nst:(d + 1) * nst]
+                dd["h0"] = st[0]
+                dd["c0"] = st[1] if rt == "lstm" else None
+            else:
+                dd["h0"] = dd["c0"] = None
+        buf["mask"] = mask
+        buf["x3d"] = x3d
+        buf["drop"] = drop
+        buf["seq"] = ops.make_rnn_seq(rt, B, T, H, buf["dirs"], mask, buf["y"], [0, H])
+        ops.rnn_seq_fwd(buf["seq"])
+        return buf["y"]
+
+    def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False):
+        """dy3d [B,T,2H]; dfinal_h: per direction gradient wrt the final h state ([B,H] or None);
+        dc_bufs: per direction [B,H] buffer holding the gradient wrt the final c state on entry and
+        the gradient wrt the initial c state on exit (LSTM).  Returns per-direction dh0 buffers.
+        Parameter gradients are accumulated into the store; dx3d (+)= input gradient if not None."""
+        B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
+        gds = []
+        for d, dd in enumerate(buf["dirs"]):
+            if buf["mask"] is not None:
+                ops.fill(dd["dy_carry"], 0.0)
+            gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
+                            dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, slab=dd["slab"], dh0=dd["dh0"]))
+        ops.rnn_seq_bwd(buf["seq"], dy3d, gds)
+        x2d = buf["x3d"].reshape(B * T, self.Din)
+        for d, dd in enumerate(buf["dirs"]):
+            g, p = self.store.g, self.store.p
+            nm = self.names[d]
+            ds3 = dd["saved"]
+            ds2 = ds3.view(B * T, -1)
+            mt = dd["mtab"] if buf["drop"] else None
+            cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
+            # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
+            hs = dd["hseq"]
+            for s0, d0, n in slot_cols(rt, H, "rec"):
+                gU = g[nm + "recurrent_kernel"][:, d0:d0 + n]
+                if T > 1:
+                    if dd["reverse"]:
+                        ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                    else:
+                        ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                if dd["h0"] is not None:
+                    t0 = T - 1 if dd["reverse"] else 0
+                    ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
+            if dx3d is not None:
+                cell_input_grad(rt, H, ds2, p[nm + "kernel"], dx3d.view(B * T, self.Din), accumulate=(dx_accumulate or d == 1),
+                                c_scale=mt, c_rpg=T)
+        return [dd["dh0"] for dd in buf["dirs"]]

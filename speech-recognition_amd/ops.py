@@ -223,10 +223,12 @@ def slab_floats(geom, B):
     return geom.Q * ((B + 15) // 16 * 16) * geom.slab_ld
 
 
-def slab_reduce(slab, geom, B, col0, ncols, out, add=None, accumulate=False):
+def slab_reduce(slab, geom, B, col0, ncols, out, add=None, accumulate=False, seed=None, drop_stream=0, drop_rate=0.0,
+                drop_ld=0, drop_off=0):
     Bpad = (B + 15) // 16 * 16
     check(lib().asr_slab_reduce(_p(slab), geom.Q, Bpad * geom.slab_ld, geom.slab_ld, col0, ncols, B, _p(add),
-                                add.stride(0) if add is not None else 0, _p(out), out.stride(0), int(accumulate), _stream()))
+                                add.stride(0) if add is not None else 0, _p(out), out.stride(0), int(accumulate),
+                                _p(seed) if drop_rate > 0 else None, drop_stream, float(drop_rate), drop_ld, drop_off, _stream()))
     return out
 
 
@@ -237,9 +239,15 @@ def rnn_cell_fwd(rnn_type, B, H, steps, seed=None):
     check(lib().asr_rnn_cell_fwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _p(seed), _stream()))
 
 
-def rnn_cell_bwd(rnn_type, B, H, steps):
+def rnn_cell_bwd(rnn_type, B, H, steps, seed=None):
     arr = (_lib.RnnStepBwd * len(steps))(*steps)
-    check(lib().asr_rnn_cell_bwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _stream()))
+    check(lib().asr_rnn_cell_bwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _p(seed), _stream()))
+
+
+def token_mask(tok, pad, out):
+    """out[i] = tok[i] != pad over contiguous int32 tokens; out uint8 with unit stride."""
+    check(lib().asr_token_mask(_p(tok), tok.numel(), int(pad), _p(out), 1, _stream()))
+    return out
 
 
 # ----------------------------------------------------------------------------------------- conv

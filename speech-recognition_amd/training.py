@@ -1,0 +1,154 @@
+"""The training step of run/train.py:158-217 (Keras ``compile`` + ``fit`` inner loop) on MI355X.
+
+One step = [audio front end] -> forward(training=True) -> loss -> backward -> (data-parallel gradient
+all-reduce) -> Adam with the LRScheduler -> advance the step counter / dropout seed.  Everything
+between the host->device copy of the batch and the parameter update is kernels of libasr_mi355x.so
+on one HIP stream; with ``use_graph`` the sequence is captured once per input shape into hipGraphs
+and replayed, which removes the per-launch host cost of the ~10^3-10^4 small dependent kernels of
+the recurrent sweeps (launch boundaries inside a graph cost ~1.5 us on MI355X).
+
+Data parallelism (utils.py:148-149 MirroredStrategy in the reference): one process per GPU; the flat
+gradient buffer is split into buckets in the order the backward pass completes them (decoder side
+first), and bucket k is all-reduced over RCCL on a side stream while backward segment k+1 runs.
+Each rank scales its loss gradient by 1/world_size, so the summed gradient is the replica mean
+([TF-sem] Keras scales SUM_OVER_BATCH_SIZE losses by 1/num_replicas).
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from . import rng as R
+
+
+class TrainStep:
+    def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
+                 beta1=0.9, beta2=0.999, eps=1e-7):
+        """model: LAS or DeepSpeech2 (built lazily on the first batch); lr_schedule: utils.LRScheduler;
+        frontend: LogmelPlan when batches arrive as raw audio, None when they are feature tensors."""
+        self.model, self.frontend, self.strategy = model, frontend, strategy
+        self.sched_host = lr_schedule
+        self.sched = lr_schedule.device_schedule()
+        self.use_graph = use_graph
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.world = strategy.world_size if strategy is not None else 1
+        self.group = getattr(strategy, "group", None)
+        self._shapes: Dict[tuple, dict] = {}
+        self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
+        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.iterations = 0
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _ctx(self, audio, n_samples, tokens):
+        key = (tuple(audio.shape), tuple(tokens.shape))
+        if key in self._shapes:
+            return self._shapes[key]
+        dev = self.model.device
+        c = dict(audio=torch.empty(audio.shape, dtype=torch.float32, device=dev),
+                 n_samples=torch.empty(audio.shape[0], dtype=torch.int32, device=dev) if self.frontend else None,
+                 tokens=torch.empty(tokens.shape, dtype=torch.int32, device=dev), graphs={}, warm=set())
+        B = audio.shape[0]
+        if self.frontend is not None:
+            T = self.frontend.num_frames(audio.shape[1])
+            c["feats"] = torch.empty(B, T, self.frontend.num_mel_bins, self.frontend.channels, device=dev)
+        else:
+            c["feats"] = c["audio"]
+        f = c["feats"]
+        self.model._ensure_built(f.shape[2], f.shape[3])
+        c["ws"], c["labels"] = self.model.train_workspace(B, f.shape[1], tokens.shape[1])
+        self._shapes[key] = c
+        return c
+
+    # ------------------------------------------------------------------------------------------ pieces
+    def _fwd_loss(self, c, teacher):
+        m = self.model
+        if self.frontend is not None:
+            self.frontend(c["audio"], c["n_samples"], c["feats"].shape[1], seed=m.seed if self.frontend.cfg.sa_enable else None,
+                          out=c["feats"])
+        ops.fill(m.store.grad, 0.0)
+        m.pack_weights()
+        m.forward_ws(c["ws"], c["feats"], True, teacher)
+        m.loss_and_grad(c["ws"], c["labels"], 1.0 / self.world)
+
+    def _update(self):
+        m = self.model
+        ops.adam_step(m.store.flat, m.store.grad, m.store.adam_m, m.store.adam_v, m.state, self.sched, self.beta1, self.beta2, self.eps)
+        ops.advance_state(m.state)
+
+    def _segments(self, c, teacher):
+        """The step as a list of stream-ordered callables; gradient bucket k is complete after
+        segment k+1 (segment 0 = front end + forward + loss)."""
+        segs = [lambda: self._fwd_loss(c, teacher)]
+        segs += self.model.backward_segments(c["ws"], c["feats"])
+        return segs
+
+    def _run_segment(self, c, teacher, k, fn):
+        if not self.use_graph:
+            fn()
+            return
+        gkey = (teacher, k)
+        if gkey not in c["warm"]:        # first call per segment runs eagerly (allocations, lazy init)
+            fn()
+            c["warm"].add(gkey)
+            return
+        if gkey not in c["graphs"]:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                fn()
+            c["graphs"][gkey] = g
+        c["graphs"][gkey].replay()
+
+    # ------------------------------------------------------------------------------------------ step
+    def step(self, audio, n_samples, tokens, use_teacher_forcing: Optional[bool] = None):
+        """audio: f32 [B, N] raw samples (frontend given) or f32 [B,T,F,C] features; n_samples: i32 [B]
+        (ignored for features); tokens: i32 [B, L] full token rows (BOS ... EOS, zero padded).
+        Returns the workspace whose ``stats`` tensor holds [loss, #correct, #kept] on the device."""
+        m = self.model
+        c = self._ctx(audio, n_samples, tokens)
+        if use_teacher_forcing is None:
+            use_teacher_forcing = m.draw_teacher_forcing()
+        teacher = bool(use_teacher_forcing)
+        with torch.cuda.stream(self.stream):
+            c["audio"].copy_(audio, non_blocking=True)
+            if c["n_samples"] is not None:
+                c["n_samples"].copy_(n_samples, non_blocking=True)
+            c["tokens"].copy_(tokens, non_blocking=True)
+            m.set_targets(c["ws"], c["tokens"], c["labels"])   # layout copies of the token rows (not captured)
+            segs = self._segments(c, teacher)
+            handles = []
+            buckets = m.store.bucket_views()
+            for k, fn in enumerate(segs):
+                self._run_segment(c, teacher, k, fn)
+                if self.world > 1 and k >= 1:
+                    handles.append(self._allreduce_async(buckets[k - 1] if k - 1 < len(buckets) else None))
+            for h in handles:
+                if h is not None:
+                    self.stream.wait_event(h)
+            self._run_segment(c, teacher, "update", self._update)
+        m.weights_changed()
+        self.iterations += 1
+        return c["ws"]
+
+    def _allreduce_async(self, bucket):
+        """Sum one gradient bucket across ranks on the communication stream; returns an event."""
+        if bucket is None:
+            return None
+        import torch.distributed as dist
+        ready = torch.cuda.Event()
+        ready.record(self.stream)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        return done
+
+    def synchronize(self):
+        self.stream.synchronize()
+        if self.comm_stream is not None:
+            self.comm_stream.synchronize()
+
+    def read_stats(self, ws):
+        """Host copy of [loss, #correct, #kept] (synchronises)."""
+        self.synchronize()
+        return [float(v) for v in ws.stats[:3].cpu()]
