@@ -10,26 +10,65 @@
 // so one step is two small kernels: scores (wave-level dot products over all 256 CUs) and
 // softmax + context (block-level max/sum reductions, one workgroup per (batch row, 64-column slice)).
 // The backward step mirrors them: dp = dctx . enc ; ds = p (dp - <p,dp>) ; dh = ds . Kq.
+// These kernels are latency-bound (a step moves ~25 MB): every wave issues the loads of several
+// independent rows before it reduces any of them.
 #include "common.h"
 
-// e[b,t] = h[b] . Kq[b,t,:] + s0[b,t] - 1e9 (1 - mask[b,t]).   grid (ceil(T/32), B); a wave does 8 rows.
-__global__ __launch_bounds__(256) void attn_scores_kernel(const float* h, long ldh, const float* Kq, const float* s0, const uint8_t* mask,
-                                                          int T, int Hd, float* e) {
+#define ATT_RPW 4   // rows per wave in the dot-product kernels
+#define ATT_UNR 8   // independent loads in flight per lane in the weighted-sum kernels
+
+// out[b,t] = v[b] . M[b,t,:] (+ s0[b,t]) (- 1e9 (1 - mask[b,t]))     grid (ceil(T/16), B)
+template <bool VEC>
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* v, long ldv, const float* M, const float* s0, const uint8_t* mask,
+                                                          int T, int K, float* out) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float* hb = h + (long)b * ldh;
-  for (int i = 0; i < 8; ++i) {
-    const int t = blockIdx.x * 32 + w * 8 + i;
-    if (t >= T) break;
-    const float* kr = Kq + ((long)b * T + t) * Hd;
-    float s = 0.f;
-    for (int k = lane; k < Hd; k += 64) s = fmaf(hb[k], kr[k], s);
-    s = wave_sum(s);
-    if (lane == 0) {
-      float v = s + (s0 ? s0[(long)b * T + t] : 0.f);
-      v -= 1e9f * (1.0f - (mask[(long)b * T + t] ? 1.0f : 0.0f));
-      e[(long)b * T + t] = v;
+  const float* vb = v + (long)b * ldv;
+  const int t0 = blockIdx.x * (4 * ATT_RPW) + w * ATT_RPW;
+  float s[ATT_RPW];
+#pragma unroll
+  for (int r = 0; r < ATT_RPW; ++r) s[r] = 0.f;
+  if (VEC) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 hv = *reinterpret_cast<const float4*>(vb + k);
+      float4 kv[ATT_RPW];
+#pragma unroll
+      for (int r = 0; r < ATT_RPW; ++r)
+        kv[r] = (t0 + r < T) ? *reinterpret_cast<const float4*>(M + ((long)b * T + t0 + r) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < ATT_RPW; ++r) s[r] += hv.x * kv[r].x + hv.y * kv[r].y + hv.z * kv[r].z + hv.w * kv[r].w;
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float hv = vb[k];
+#pragma unroll
+      for (int r = 0; r < ATT_RPW; ++r)
+        if (t0 + r < T) s[r] = fmaf(hv, M[((long)b * T + t0 + r) * K + k], s[r]);
     }
   }
+#pragma unroll
+  for (int r = 0; r < ATT_RPW; ++r) {
+    const float tot = wave_sum(s[r]);
+    const int t = t0 + r;
+    if (lane == 0 && t < T) {
+      float val = tot + (s0 ? s0[(long)b * T + t] : 0.f);
+      if (mask) val -= 1e9f * (1.0f - (mask[(long)b * T + t] ? 1.0f : 0.0f));
+      out[(long)b * T + t] = val;
+    }
+  }
+}
+
+// acc[c] = sum_t wgt[t] X[b,t,c]  for this block's 64 columns, 4 waves striding t, ATT_UNR loads in flight
+__device__ __forceinline__ float weighted_colsum(const float* wgt, const float* Xb, int T, int D, int c, int w) {
+  float acc = 0.f;
+  if (c >= D) return 0.f;
+  for (int t0 = w; t0 < T; t0 += 4 * ATT_UNR) {
+    float x[ATT_UNR];
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) { const int t = t0 + 4 * i; x[i] = t < T ? Xb[(long)t * D + c] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) { const int t = t0 + 4 * i; if (t < T) acc = fmaf(wgt[t], x[i], acc); }
+  }
+  return acc;
 }
 
 // p = softmax(e[b,:]); ctx[b, c0:c0+64] = sum_t p[t] enc[b,t,c0:c0+64].   grid (ceil(D/64), B)
@@ -50,27 +89,9 @@ __global__ __launch_bounds__(256) void attn_softmax_ctx_kernel(const float* e, c
   __syncthreads();
   if (blockIdx.x == 0 && p_out)
     for (int t = threadIdx.x; t < T; t += 256) p_out[(long)b * T + t] = p[t] * inv;
-  float acc = 0.f;
-  if (c < D)
-    for (int t = w; t < T; t += 4) acc = fmaf(p[t], enc[((long)b * T + t) * D + c], acc);
-  part[w * 64 + (threadIdx.x & 63)] = acc;
+  part[w * 64 + (threadIdx.x & 63)] = weighted_colsum(p, enc + (long)b * T * D, T, D, c, w);
   __syncthreads();
   if (w == 0 && c < D) ctx[(long)b * ldctx + c] = (part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x]) * inv;
-}
-
-// dp[b,t] = dctx[b] . enc[b,t,:]     grid (ceil(T/32), B)
-__global__ __launch_bounds__(256) void attn_bwd_dp_kernel(const float* dctx, long ldd, const float* enc, int T, int D, float* dp) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float* db = dctx + (long)b * ldd;
-  for (int i = 0; i < 8; ++i) {
-    const int t = blockIdx.x * 32 + w * 8 + i;
-    if (t >= T) break;
-    const float* er = enc + ((long)b * T + t) * D;
-    float s = 0.f;
-    for (int k = lane; k < D; k += 64) s = fmaf(db[k], er[k], s);
-    s = wave_sum(s);
-    if (lane == 0) dp[(long)b * T + t] = s;
-  }
 }
 
 // ds = p (dp - <p, dp>);  dh[b, c0:c0+64] (+)= sum_t ds[t] Kq[b,t,c0:c0+64].   grid (ceil(Hd/64), B)
@@ -90,10 +111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dh_kernel(const float* p, const 
     if (blockIdx.x == 0 && ds_out) ds_out[(long)b * T + t] = v;
   }
   __syncthreads();
-  float acc = 0.f;
-  if (c < Hd)
-    for (int t = w; t < T; t += 4) acc = fmaf(ds[t], Kq[((long)b * T + t) * Hd + c], acc);
-  part[w * 64 + (threadIdx.x & 63)] = acc;
+  part[w * 64 + (threadIdx.x & 63)] = weighted_colsum(ds, Kq + (long)b * T * Hd, T, Hd, c, w);
   __syncthreads();
   if (w == 0 && c < Hd) {
     const float v = part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
@@ -103,6 +121,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dh_kernel(const float* p, const 
 }
 
 static size_t attn_smem(int T) { return sizeof(float) * ((size_t)T + 256 + 16); }
+static inline bool vec4_ok(const void* a, long lda, const void* m, int K) {
+  return (K % 4 == 0) && (lda % 4 == 0) && (((uintptr_t)a | (uintptr_t)m) & 15) == 0;
+}
+static void launch_rowdot(const float* v, long ldv, const float* M, const float* s0, const uint8_t* mask, int B, int T, int K, float* out,
+                          hipStream_t st) {
+  dim3 grid((unsigned)asr_cdiv(T, 4 * ATT_RPW), (unsigned)B);
+  if (vec4_ok(v, ldv, M, K)) hipLaunchKernelGGL(attn_rowdot_kernel<true>, grid, dim3(256), 0, st, v, ldv, M, s0, mask, T, K, out);
+  else hipLaunchKernelGGL(attn_rowdot_kernel<false>, grid, dim3(256), 0, st, v, ldv, M, s0, mask, T, K, out);
+}
 
 // One decoder step of attention, forward.  h [B,Hd] (row stride ldh), Kq [B,T,Hd], s0 [B,T] or NULL,
 // mask [B,T] u8, enc [B,T,D].  Outputs: e scratch [B,T], p [B,T] (saved for backward), ctx [B,D] (row stride ldctx).
@@ -112,7 +139,7 @@ extern "C" int asr_attn_step_fwd(const float* h, long ldh, const float* Kq, cons
   ASR_CHECK(B > 0 && T > 0 && Hd > 0 && D > 0, ASR_ERR_SHAPE, "asr_attn_step_fwd: bad shape");
   ASR_CHECK(attn_smem(T) <= 64 * 1024, ASR_ERR_SHAPE, "asr_attn_step_fwd: T=%d too long for the LDS softmax (max ~16000 frames)", T);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)asr_cdiv(T, 32), (unsigned)B), dim3(256), 0, st, h, ldh, Kq, s0, mask, T, Hd, e);
+  launch_rowdot(h, ldh, Kq, s0, mask, B, T, Hd, e, st);
   hipLaunchKernelGGL(attn_softmax_ctx_kernel, dim3((unsigned)asr_cdiv(D, 64), (unsigned)B), dim3(256), attn_smem(T), st, (const float*)e, enc,
                      T, D, p, ctx, ldctx);
   ASR_LAUNCH_CHECK();
@@ -126,7 +153,7 @@ extern "C" int asr_attn_step_bwd(const float* dctx, long lddctx, const float* p,
   ASR_CHECK(dctx && p && Kq && enc && dp && ds && dh, ASR_ERR_ARG, "asr_attn_step_bwd: null argument");
   ASR_CHECK(B > 0 && T > 0 && Hd > 0 && D > 0 && attn_smem(T) <= 64 * 1024, ASR_ERR_SHAPE, "asr_attn_step_bwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_bwd_dp_kernel, dim3((unsigned)asr_cdiv(T, 32), (unsigned)B), dim3(256), 0, st, dctx, lddctx, enc, T, D, dp);
+  launch_rowdot(dctx, lddctx, enc, nullptr, nullptr, B, T, D, dp, st);
   hipLaunchKernelGGL(attn_bwd_dh_kernel, dim3((unsigned)asr_cdiv(Hd, 64), (unsigned)B), dim3(256), attn_smem(T), st, p, (const float*)dp, Kq,
                      T, Hd, ds, dh, lddh, accumulate);
   ASR_LAUNCH_CHECK();

@@ -29,6 +29,12 @@ static __host__ __device__ inline int cell_ngates(int cell) { return cell == CEL
 static __host__ __device__ inline int cell_nsaved(int cell) { return cell == CELL_RNN ? 1 : 4; }
 
 // ------------------------------------------------------------------------------------------ pack
+// The packed K axis is the concatenation of the segments, each padded to a multiple of 16 ("blocks").
+// Forward image  Wp [Q][KB][64 lanes][4]: lane (lq = lane>>4, slot = lane&15), element e holds
+//   W[k = 16*blk + 4*lq + e][slot] - so one float4 per lane feeds 4 consecutive MFMA 16x16x4 steps and
+//   matches a float4 of the activation row loaded by the same lane (the k labelling inside a block is
+//   free as long as A and B agree).
+// Backward image Wpb[Q][KB][64 lanes][4]: lane (lq, li), element s4 holds W[k = 16*blk + li][slot = 4*s4 + lq].
 struct PackArgs {
   const float* W[ASR_RNN_MAXSEG];
   long ldw[ASR_RNN_MAXSEG];
@@ -36,18 +42,18 @@ struct PackArgs {
   int ks0[ASR_RNN_MAXSEG];
   int is_rec[ASR_RNN_MAXSEG];
   int nseg, KSt, NT, H, Q, cell;
-  float* Wp;   // [Q][KSt][64]      forward fragments:  lane -> (k = 4ks + lane>>4, slot = lane&15)
-  float* Wpb;  // [Q][NT][4][64]    backward fragments: lane -> (slot = 4s4 + lane>>4, kcol = 16nt + lane&15)
+  float* Wp;
+  float* Wpb;
 };
 
 __device__ __forceinline__ float pack_value(const PackArgs& a, int q, int kcol, int slot) {
   // kcol indexes the packed (segment-padded) K axis
-  const int ks = kcol >> 2;
+  const int blk = kcol >> 4;
   int s = -1;
   for (int i = 0; i < a.nseg; ++i)
-    if (ks >= a.ks0[i] && ks < a.ks0[i] + (a.K[i] + 3) / 4) s = i;
+    if (blk >= a.ks0[i] && blk < a.ks0[i] + (a.K[i] + 15) / 16) s = i;
   if (s < 0) return 0.f;
-  const int k = kcol - 4 * a.ks0[s];
+  const int k = kcol - 16 * a.ks0[s];
   const int g = slot >> 2, u = slot & 3, j = 4 * q + u;
   if (k >= a.K[s] || j >= a.H) return 0.f;
   const float* W = a.W[s];
@@ -62,27 +68,20 @@ __device__ __forceinline__ float pack_value(const PackArgs& a, int q, int kcol, 
 }
 
 __global__ void rnn_pack_kernel(PackArgs a) {
-  const long nf = (long)a.Q * a.KSt * 64, nb = (long)a.Q * a.NT * 4 * 64;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (long)gridDim.x * blockDim.x) {
-    if (i < nf) {
-      const int lane = (int)(i & 63);
-      const long r = i >> 6;
-      const int ks = (int)(r % a.KSt), q = (int)(r / a.KSt);
-      a.Wp[i] = pack_value(a, q, 4 * ks + (lane >> 4), lane & 15);
-    } else {
-      const long i2 = i - nf;
-      const int lane = (int)(i2 & 63);
-      long r = i2 >> 6;
-      const int s4 = (int)(r & 3); r >>= 2;
-      const int nt = (int)(r % a.NT), q = (int)(r / a.NT);
-      a.Wpb[i2] = pack_value(a, q, 16 * nt + (lane & 15), 4 * s4 + (lane >> 4));
-    }
+  const long nf = (long)a.Q * a.KSt * 256;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * nf; i += (long)gridDim.x * blockDim.x) {
+    const long i2 = i < nf ? i : i - nf;
+    const int e = (int)(i2 & 3), lane = (int)((i2 >> 2) & 63);
+    const long r = i2 >> 8;
+    const int blk = (int)(r % a.KSt), q = (int)(r / a.KSt);
+    if (i < nf) a.Wp[i2] = pack_value(a, q, 16 * blk + 4 * (lane >> 4) + e, lane & 15);
+    else a.Wpb[i2] = pack_value(a, q, 16 * blk + (lane & 15), 4 * e + (lane >> 4));
   }
 }
 
 // ------------------------------------------------------------------------------------------ forward step
 struct FwdSeg {
-  const float* x; long ld; int K; int ks0;
+  const float* x; long ld; int K; int ks0; int vec;
   int drop; uint32_t drop_stream; float drop_rate; long drop_ld; int drop_off;
 };
 struct FwdDir {
@@ -102,6 +101,8 @@ struct FwdDir {
 };
 struct FwdArgs { FwdDir d[2]; int B, H; const uint32_t* seed; };
 
+#define RNN_CH 4  // 16-wide K blocks a wave keeps in flight (loads first, then the MFMAs)
+
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   __shared__ float part[4][16 * 17];
@@ -112,22 +113,55 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   const int H = a.H, B = a.B;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* wp = d.Wp + (long)q * d.KSt * 64 + lane;
+  const float4* wp = reinterpret_cast<const float4*>(d.Wp) + (long)q * d.KSt * 64 + lane;
   const int brow = b0 + li;
   const uint32_t seedv = a.seed ? a.seed[0] : 0u;
   for (int s = 0; s < d.nseg; ++s) {
     const FwdSeg& sg = d.seg[s];
-    const int nks = (sg.K + 3) >> 2;
-    const AsrRngKey key = asr_rng_key(seedv, sg.drop_stream);
-    const uint32_t thr = asr_drop_threshold(sg.drop_rate);
-    const float dscale = 1.f / (1.f - sg.drop_rate);
-#pragma unroll 4
-    for (int ks = wave; ks < nks; ks += 4) {
-      const int k = 4 * ks + lq;
-      float av = (sg.x != nullptr && brow < B && k < sg.K) ? sg.x[(long)brow * sg.ld + k] : 0.f;
-      if (sg.drop) av *= asr_drop_mult(key, (uint32_t)((long)brow * sg.drop_ld + sg.drop_off + k), thr, dscale);
-      const float bv = wp[(long)(sg.ks0 + ks) * 64];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    const int nb = (sg.K + 15) >> 4;
+    const float* xr = sg.x ? sg.x + (long)brow * sg.ld : nullptr;
+    const bool rowok = sg.x != nullptr && brow < B;
+    for (int j0 = wave; j0 < nb; j0 += 4 * RNN_CH) {
+      float4 av[RNN_CH], bv[RNN_CH];
+#pragma unroll
+      for (int i = 0; i < RNN_CH; ++i) {
+        const int jb = j0 + 4 * i;
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jb < nb) {
+          const int k = 16 * jb + 4 * lq;
+          bv[i] = wp[(long)(sg.ks0 + jb) * 64];
+          if (rowok) {
+            if (sg.vec && k + 3 < sg.K) av[i] = *reinterpret_cast<const float4*>(xr + k);
+            else {
+              av[i].x = k < sg.K ? xr[k] : 0.f;
+              av[i].y = k + 1 < sg.K ? xr[k + 1] : 0.f;
+              av[i].z = k + 2 < sg.K ? xr[k + 2] : 0.f;
+              av[i].w = k + 3 < sg.K ? xr[k + 3] : 0.f;
+            }
+          }
+        }
+      }
+      if (sg.drop) {
+        const AsrRngKey key = asr_rng_key(seedv, sg.drop_stream);
+        const uint32_t thr = asr_drop_threshold(sg.drop_rate);
+        const float dscale = 1.f / (1.f - sg.drop_rate);
+#pragma unroll
+        for (int i = 0; i < RNN_CH; ++i) {
+          const uint32_t idx = (uint32_t)((long)brow * sg.drop_ld + sg.drop_off + 16 * (j0 + 4 * i) + 4 * lq);
+          av[i].x *= asr_drop_mult(key, idx, thr, dscale);
+          av[i].y *= asr_drop_mult(key, idx + 1, thr, dscale);
+          av[i].z *= asr_drop_mult(key, idx + 2, thr, dscale);
+          av[i].w *= asr_drop_mult(key, idx + 3, thr, dscale);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RNN_CH; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
 
 // ------------------------------------------------------------------------------------------ backward step
 struct BwdDir {
-  int KSt, NT;             // packed K steps; slab n-tiles (NT*16 >= 4*KSt)
+  int KSt, NT;             // packed 16-wide K blocks (NT == KSt: one slab column tile per block)
   const float* Wpb;
   // gradient wrt the state h leaving this cell:  sum_q slabA[q][b][colA + j]  +  addA[b][j]
   const float* slabA; int QA; long slabA_qstride; long slabA_ld; int colA;
@@ -205,10 +239,23 @@ struct BwdDir {
   const float* c_prev; long c_prev_ld; // LSTM
   const float* c_out; long c_out_ld;   // LSTM: c after this step
   float* dslots; long dslots_ld;       // [B][NS*H] gradient wrt the gate pre-activation sums (may alias saved)
-  float* slab_out; long slab_out_qstride; long slab_out_ld;  // [Q][Bpad][NT*16]
+  float* slab_out; long slab_out_qstride; long slab_out_ld;  // [Q][Bpad][16*KSt]
   int hcol;                // first packed column of the recurrent segment
 };
 struct BwdArgs { BwdDir d[2]; int B, H; const uint32_t* seed; };
+
+// sum over q' = wave, wave+4, ... of slab[q'][b][col]: independent loads issued 8 at a time
+__device__ __forceinline__ float slab_partial(const float* slab, int Q, long qstride, long off, int wave) {
+  float s = 0.f;
+  for (int q0 = wave; q0 < Q; q0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int qq = q0 + 4 * i; v[i] = qq < Q ? slab[(long)qq * qstride + off] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  return s;
+}
 
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
@@ -224,11 +271,20 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
   const int b = b0 + bi, j = 4 * q + u;
   const bool live = b < B && j < H;
 
-  // 1. slab reduction, spread over the 4 waves: wave w sums q' = w, w+4, ...   (dh in .x, dy in .y)
+  // backward-image fragments of this workgroup's K blocks: issue the loads before anything else
+  const float4* wb = reinterpret_cast<const float4*>(d.Wpb) + (long)q * d.KSt * 64 + lane;
+  float4 bw0[RNN_CH];
+#pragma unroll
+  for (int i = 0; i < RNN_CH; ++i) {
+    const int nt = wave + 4 * i;
+    bw0[i] = (d.slab_out != nullptr && nt < d.KSt) ? wb[(long)nt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // 1. slab reduction, spread over the 4 waves
   float sa = 0.f, sb = 0.f;
   if (live) {
-    if (d.slabA) for (int qq = wave; qq < d.QA; qq += 4) sa += d.slabA[(long)qq * d.slabA_qstride + (long)b * d.slabA_ld + d.colA + j];
-    if (d.slabB) for (int qq = wave; qq < d.QB; qq += 4) sb += d.slabB[(long)qq * d.slabB_qstride + (long)b * d.slabB_ld + d.colB + j];
+    if (d.slabA) sa = slab_partial(d.slabA, d.QA, d.slabA_qstride, (long)b * d.slabA_ld + d.colA + j, wave);
+    if (d.slabB) sb = slab_partial(d.slabB, d.QB, d.slabB_qstride, (long)b * d.slabB_ld + d.colB + j, wave);
   }
   red[wave][lane] = sa;
   __syncthreads();
@@ -300,40 +356,57 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
   float av[4];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) av[s4] = dp[li * 17 + 4 * s4 + lq];
-  for (int nt = wave; nt < d.NT; nt += 4) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* wb = d.Wpb + ((long)q * d.NT + nt) * 4 * 64 + lane;
+  for (int n0 = wave; n0 < d.KSt; n0 += 4 * RNN_CH) {
+    float4 bw[RNN_CH];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], wb[s4 * 64], acc, 0, 0, 0);
-    const int col = nt * 16 + li;
-    const int own = col - d.hcol - 4 * q;  // 0..3 when this column is one of the owned units' h columns
+    for (int i = 0; i < RNN_CH; ++i) {
+      const int nt = n0 + 4 * i;
+      bw[i] = n0 == wave ? bw0[i] : (nt < d.KSt ? wb[(long)nt * 64] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = lq * 4 + r;
-      float v = acc[r];
-      if (own >= 0 && own < 4) v += direct[row * 4 + own];
-      d.slab_out[(long)q * d.slab_out_qstride + (long)(b0 + row) * d.slab_out_ld + col] = v;
+    for (int i = 0; i < RNN_CH; ++i) {
+      const int nt = n0 + 4 * i;
+      if (nt >= d.KSt) continue;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bw[i].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bw[i].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bw[i].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bw[i].w, acc, 0, 0, 0);
+      const int col = nt * 16 + li;
+      const int own = col - d.hcol - 4 * q;  // 0..3 when this column is one of the owned units' h columns
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lq * 4 + r;
+        float v = acc[r];
+        if (own >= 0 && own < 4) v += direct[row * 4 + own];
+        d.slab_out[(long)q * d.slab_out_qstride + (long)(b0 + row) * d.slab_out_ld + col] = v;
+      }
     }
   }
 }
 
-// sum of slabs: out[b][c] (+)= sum_q slab[q][b][col0 + c] (+ add[b][c])
-__global__ void slab_reduce_kernel(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B,
-                                   const float* add, long add_ld, float* out, long out_ld, int accumulate,
-                                   const uint32_t* seed, uint32_t drop_stream, float drop_rate, long drop_ld, int drop_off) {
-  const long n = (long)B * ncols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / ncols), c = (int)(i % ncols);
-    float s = 0.f;
-    for (int q = 0; q < Q; ++q) s += slab[(long)q * qstride + (long)b * ld + col0 + c];
-    if (drop_rate > 0.f) {
-      const AsrRngKey key = asr_rng_key(seed[0], drop_stream);
-      s *= asr_drop_mult(key, (uint32_t)((long)b * drop_ld + drop_off + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
-    }
-    if (add) s += add[(long)b * add_ld + c];
-    float* o = out + (long)b * out_ld + c;
-    *o = accumulate ? *o + s : s;
+// sum of slabs: out[b][c] (+)= (sum_q slab[q][b][col0 + c]) * drop (+ add[b][c]).
+// Block = 64 outputs x 4 q-lanes; each thread keeps 8 independent loads in flight.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B,
+                                                          const float* add, long add_ld, float* out, long out_ld, int accumulate,
+                                                          const uint32_t* seed, uint32_t drop_stream, float drop_rate, long drop_ld,
+                                                          int drop_off) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + l;
+  const bool live = i < (long)B * ncols;
+  const int b = live ? (int)(i / ncols) : 0, c = live ? (int)(i % ncols) : 0;
+  red[w][l] = live ? slab_partial(slab, Q, qstride, (long)b * ld + col0 + c, w) : 0.f;
+  __syncthreads();
+  if (w != 0 || !live) return;
+  float s = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+  if (drop_rate > 0.f) {
+    const AsrRngKey key = asr_rng_key(seed[0], drop_stream);
+    s *= asr_drop_mult(key, (uint32_t)((long)b * drop_ld + drop_off + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
   }
+  if (add) s += add[(long)b * add_ld + c];
+  float* o = out + (long)b * out_ld + c;
+  *o = accumulate ? *o + s : s;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -346,12 +419,12 @@ extern "C" int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr
   g->Q = asr_cdiv(H, 4);
   int ks = 0;
   for (int i = 0; i < ASR_RNN_MAXSEG; ++i) g->ks0[i] = 0;
-  for (int i = 0; i < nseg; ++i) { g->ks0[i] = ks; ks += asr_cdiv(K[i], 4); }
+  for (int i = 0; i < nseg; ++i) { g->ks0[i] = ks; ks += asr_cdiv(K[i], 16); }
   g->KSt = ks;
-  g->NT = asr_cdiv(4L * ks, 16);
-  g->wp_floats = (long)g->Q * g->KSt * 64;
-  g->wpb_floats = (long)g->Q * g->NT * 4 * 64;
-  g->slab_ld = g->NT * 16;
+  g->NT = ks;
+  g->wp_floats = (long)g->Q * g->KSt * 256;
+  g->wpb_floats = (long)g->Q * g->KSt * 256;
+  g->slab_ld = g->KSt * 16;
   return ASR_OK;
 }
 
@@ -375,6 +448,7 @@ static void fill_fwd_dir(FwdDir* d, const asr_rnn_step_fwd* s) {
   d->nseg = s->nseg; d->KSt = s->KSt; d->Wp = s->Wp;
   for (int i = 0; i < s->nseg; ++i) {
     d->seg[i].x = s->seg_x[i]; d->seg[i].ld = s->seg_ld[i]; d->seg[i].K = s->seg_K[i]; d->seg[i].ks0 = s->seg_ks0[i];
+    d->seg[i].vec = (((uintptr_t)s->seg_x[i] & 15) == 0) && (s->seg_ld[i] % 4 == 0);
     d->seg[i].drop = s->seg_drop_rate[i] > 0.f; d->seg[i].drop_stream = s->seg_drop_stream[i];
     d->seg[i].drop_rate = s->seg_drop_rate[i]; d->seg[i].drop_ld = s->seg_drop_ld[i]; d->seg[i].drop_off = s->seg_drop_off[i];
   }
@@ -449,6 +523,7 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
         fd.y_prev = s->y + (long)tp * s->y_ld + s->y_col[d]; fd.y_prev_ld = (long)T * s->y_ld;
       }
       fd.seg[0].x = fd.h_prev; fd.seg[0].ld = fd.h_prev_ld; fd.seg[0].K = H; fd.seg[0].ks0 = 0;
+      fd.seg[0].vec = (((uintptr_t)fd.h_prev & 15) == 0) && (fd.h_prev_ld % 4 == 0);
       fd.mask = s->mask ? s->mask + t : nullptr; fd.mask_ld = T;
       fd.h_out = hseq + (long)t * H; fd.h_out_ld = (long)T * H;
       fd.c_out = lstm ? cseq + (long)t * H : nullptr; fd.c_out_ld = (long)T * H;
@@ -564,7 +639,7 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
     if (gs->dh0[d]) {
       const float* slab0 = gs->slab[d];  // step 0 -> parity 0
       const long n = (long)B * H;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, st, slab0, g.Q,
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab0, g.Q,
                          qstride, (long)g.slab_ld, 0, H, B, (const float*)nullptr, 0L, gs->dh0[d], gs->dh0_ld[d], 0,
                          (const uint32_t*)nullptr, 0u, 0.f, 0L, 0);
     }
@@ -579,7 +654,7 @@ extern "C" int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, 
   ASR_CHECK(slab && out && Q > 0 && B > 0 && ncols > 0, ASR_ERR_ARG, "asr_slab_reduce: bad argument");
   ASR_CHECK(!(drop_rate > 0.f && !seed), ASR_ERR_ARG, "asr_slab_reduce: dropout needs a device seed");
   const long n = (long)B * ncols;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slab,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, slab,
                      Q, qstride, ld, col0, ncols, B, add, add_ld, out, out_ld, accumulate, seed, drop_stream, drop_rate, drop_ld, drop_off);
   ASR_LAUNCH_CHECK();
   return ASR_OK;

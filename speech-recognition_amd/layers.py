@@ -37,7 +37,15 @@ def dense_bwd(x2d, W, dy2d, gW, gb, dx2d=None, dx_accumulate=False, a_scale=None
     if gb is not None:
         ops.colsum(dy2d, gb)
     if dx2d is not None:
-        ops.gemm(dy2d, W, dx2d, trans_b=True, accumulate=1 if dx_accumulate else 0, c_scale=c_scale, c_rpg=c_rpg)
+        M, N, Kc = dx2d.shape[0], dx2d.shape[1], dy2d.shape[1]
+        tiles = math.ceil(M / 64) * math.ceil(N / 64)
+        if tiles < 256 and Kc >= 4096 and c_scale is None and dx2d.is_contiguous():
+            # few output tiles, long reduction (vocabulary projection): partition K across workgroups
+            if not dx_accumulate:
+                ops.fill(dx2d, 0.0)
+            ops.gemm(dy2d, W, dx2d, trans_b=True, accumulate=1, split_k=max(2, min(16, Kc // 1024)))
+        else:
+            ops.gemm(dy2d, W, dx2d, trans_b=True, accumulate=1 if dx_accumulate else 0, c_scale=c_scale, c_rpg=c_rpg)
 
 
 def slot_cols(rnn_type, H, which):

@@ -495,14 +495,14 @@ class LAS(ModelProto):
                 if j < last:      # state and output both feed layer j+1 of the same step
                     nxt = self.dec_cells[j + 1].geom
                     sl = ws.dec[j + 1]["slab"][i & 1]
-                    st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 4 * nxt.ks0[1]
-                    st.slabB, st.QB, st.slabB_qstride, st.slabB_ld, st.colB = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 4 * nxt.ks0[0]
+                    st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 16 * nxt.ks0[1]
+                    st.slabB, st.QB, st.slabB_qstride, st.slabB_ld, st.colB = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 16 * nxt.ks0[0]
                     st.dropB_rate, st.dropB_stream, st.dropB_ld, st.dropB_off = rate, base + 2 + j + 1, Hd, 0
                 else:             # last layer: state feeds layer 0 + attention of step i+1; output feeds Dense(V)
                     if i < U - 1:
                         g0 = self.dec_cells[0].geom
                         sl = ws.dec[0]["slab"][(i + 1) & 1]
-                        st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), g0.Q, Bpad * g0.slab_ld, g0.slab_ld, 4 * g0.ks0[1]
+                        st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), g0.Q, Bpad * g0.slab_ld, g0.slab_ld, 16 * g0.ks0[1]
                         st.addA, st.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
                     dyl = ws.dyd[i * B:(i + 1) * B]
                     st.addB, st.addB_ld = dyl.data_ptr(), dyl.stride(0)
@@ -516,16 +516,16 @@ class LAS(ModelProto):
                 st.dslots, st.dslots_ld = sv.data_ptr(), sv.stride(0)
                 st.h_prev, st.h_prev_ld = h_in.data_ptr(), h_in.stride(0)
                 so = ws.dec[j]["slab"][i & 1]
-                st.slab_out, st.slab_out_qstride, st.slab_out_ld, st.hcol = so.data_ptr(), Bpad * geo.slab_ld, geo.slab_ld, 4 * geo.ks0[1]
+                st.slab_out, st.slab_out_qstride, st.slab_out_ld, st.hcol = so.data_ptr(), Bpad * geo.slab_ld, geo.slab_ld, 16 * geo.ks0[1]
                 ops.rnn_cell_bwd(rt, B, Hd, [st], seed)
             # context gradient = layer 0's input-segment gradient through its input dropout
             g0 = self.dec_cells[0].geom
-            ops.slab_reduce(ws.dec[0]["slab"][i & 1], g0, B, 4 * g0.ks0[0], 2 * He, ws.dctx[i], seed=seed, drop_stream=base + 2,
+            ops.slab_reduce(ws.dec[0]["slab"][i & 1], g0, B, 16 * g0.ks0[0], 2 * He, ws.dctx[i], seed=seed, drop_stream=base + 2,
                             drop_rate=rate, drop_ld=Hd + 2 * He, drop_off=Hd)
             ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False)
         # gradient wrt the decoder's initial states (= listener state projections)
         g0 = self.dec_cells[0].geom
-        ops.slab_reduce(ws.dec[0]["slab"][0], g0, B, 4 * g0.ks0[1], Hd, ws.dhs, add=ws.dh_attn)
+        ops.slab_reduce(ws.dec[0]["slab"][0], g0, B, 16 * g0.ks0[1], Hd, ws.dhs, add=ws.dh_attn)
         # ---- decoder weight gradients, batched over steps
         for j in range(self.Ld):
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"
