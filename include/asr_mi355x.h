@@ -181,6 +181,19 @@ int asr_adam_step(float* params, const float* grads, float* m, float* v, long n,
                   const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int asr_advance_state(int32_t* state, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * CTC (measure.py:24-42 CTCLoss on tf.nn.ctc_loss): labels [B, L] int32 zero(pad)-padded dense rows,
+ * label_length = count(label != pad), logit_length = T for every row, blank_index as configured
+ * (deepspeech.yml: 14).  logits [B*T, V] batch-major (row stride ld) are overwritten with
+ * grad_scale * d(mean_b nll_b / len_b) / d logits when write_grad.  stats[0] += loss (zero it first);
+ * per_sample [B] receives nll_b / len_b.  ws: asr_ctc_workspace_floats(B, T, L) floats of scratch.
+ * ------------------------------------------------------------------------------------------ */
+long asr_ctc_workspace_floats(int B, int T, int L);
+int asr_ctc_loss(float* logits, long ld, const int32_t* labels, int B, int T, int V, int L, int blank, int pad, float* ws,
+                 float* per_sample, float* stats, int write_grad, float grad_scale, void* stream);
+/* out[r, :] = x[r, :] * (mask[r] != 0)   (deepspeech2.py:176 `* mask[:, :, None]` and its gradient) */
+int asr_mask_rows(const float* x, long ldx, const uint8_t* mask, int R, int C, float* out, long ldo, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Recurrent layers: Keras LSTM / GRU(reset_after=True) / SimpleRNN with K.rnn mask semantics

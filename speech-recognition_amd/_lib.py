@@ -144,6 +144,10 @@ SIGNATURES = {
     "asr_adam_step": (C.c_int, [_P, _P, _P, _P, c_long, _P, C.POINTER(LrSchedule), C.c_float, C.c_float, C.c_float,
                                 C.c_float, _P]),
     "asr_advance_state": (C.c_int, [_P, _P]),
+    "asr_ctc_workspace_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_ctc_loss": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int,
+                               C.c_float, _P]),
+    "asr_mask_rows": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, _P, c_long, _P]),
 }
 
 _lib = None

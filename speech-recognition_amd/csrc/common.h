@@ -90,6 +90,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return r;
 }
 
-// accurate (ocml) transcendental forms: the gate math is latency-, not throughput-bound
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each, absolute
+// error of the results ~1e-7).  The gate math of a recurrent step runs on ONE wave per workgroup and
+// sits on the step's critical path, so the ~100-instruction ocml expf/tanhf forms cost ~1 us per step.
+__device__ __forceinline__ float fast_exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp_(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float t = fast_exp_(-2.f * fabsf(x));
+  return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+}

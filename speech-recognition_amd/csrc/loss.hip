@@ -1,10 +1,7 @@
-// Losses for gfx950.
-//  * masked sparse softmax cross-entropy + accuracy, forward and gradient in one pass over the logits
-//    (measure.py:4-21 SparseCategoricalCrossentropy, measure.py:45-69 SparseCategoricalAccuracy, and the
-//    Keras SUM_OVER_BATCH_SIZE mean over the kept tokens).
-//  * CTC (measure.py:24-42): see ctc kernels below.
-// HBM-bound: each logits row is read once into LDS, reduced with wave shuffles, and the gradient is
-// written once in place.
+// Masked sparse softmax cross-entropy + accuracy for gfx950, forward and gradient in one pass over the
+// logits (measure.py:4-21 SparseCategoricalCrossentropy, measure.py:45-69 SparseCategoricalAccuracy, and
+// the Keras SUM_OVER_BATCH_SIZE mean over the kept tokens).  HBM-bound: each logits row is read once
+// into LDS, reduced with wave shuffles, and the gradient is written once in place.  (CTC: ctc.hip.)
 #include "common.h"
 
 // stats layout (float): [0] sum of per-token NLL / n_valid (= the loss), [1] number of correct argmax, [2] n_valid

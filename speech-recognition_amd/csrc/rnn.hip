@@ -112,6 +112,30 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   const int q = blockIdx.x, b0 = blockIdx.y * 16;
   const int H = a.H, B = a.B;
 
+  // wave 0 owns the gate math of the 16 x 4 (row, unit) pairs: fetch its operands now, so their
+  // latency hides under the matrix product instead of following the barrier
+  const int bi = lane >> 2, u = lane & 3;
+  const int b = b0 + bi, j = 4 * q + u;
+  const bool live = b < B && j < H;
+  constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
+  bool m = true;
+  float hp = 0.f, yp = 0.f, cp = 0.f, pre[NG], br[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NG; ++g) pre[g] = 0.f;
+  if (wave == 0 && live) {
+    m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+    hp = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+    yp = d.y_prev ? d.y_prev[(long)b * d.y_prev_ld + j] : 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float v = d.pre ? d.pre[(long)b * d.pre_ld + (long)g * H + j] : 0.f;
+      if (d.bias) v += d.bias[(long)g * H + j];
+      pre[g] = v;
+    }
+    if (CELL == CELL_LSTM) cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+    if (CELL == CELL_GRU && d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
+  }
+
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float4* wp = reinterpret_cast<const float4*>(d.Wp) + (long)q * d.KSt * 64 + lane;
   const int brow = b0 + li;
@@ -168,28 +192,13 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   for (int r = 0; r < 4; ++r) part[wave][(lq * 4 + r) * 17 + li] = acc[r];
   __syncthreads();
   if (wave != 0) return;
-
-  const int bi = lane >> 2, u = lane & 3;
-  const int b = b0 + bi, j = 4 * q + u;
-  if (b >= B || j >= H) return;
+  if (!live) return;
   float s[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     s[g] = part[0][bi * 17 + g * 4 + u] + part[1][bi * 17 + g * 4 + u] + part[2][bi * 17 + g * 4 + u] + part[3][bi * 17 + g * 4 + u];
-  const bool m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
-  const float hp = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
-  const float yp = d.y_prev ? d.y_prev[(long)b * d.y_prev_ld + j] : 0.f;
-  constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
-  float pre[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    float v = d.pre ? d.pre[(long)b * d.pre_ld + (long)g * H + j] : 0.f;
-    if (d.bias) v += d.bias[(long)g * H + j];
-    pre[g] = v;
-  }
   float hn, cn = 0.f;
   if (CELL == CELL_LSTM) {
-    const float cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
     const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
     const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
     const float c2 = fg * cp + ig * gg;
@@ -201,8 +210,6 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
     }
     if (d.c_out) d.c_out[(long)b * d.c_out_ld + j] = cn;
   } else if (CELL == CELL_GRU) {
-    float br[3] = {0.f, 0.f, 0.f};
-    if (d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
     const float z = sigmoidf_(pre[0] + s[0] + br[0]);
     const float r = sigmoidf_(pre[1] + s[1] + br[1]);
     const float arh = s[3] + br[2];
@@ -260,6 +267,7 @@ __device__ __forceinline__ float slab_partial(const float* slab, int Q, long qst
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
   __shared__ float red[4][64];
+  __shared__ float red2[4][64];
   __shared__ float dp[16 * 17];
   __shared__ float direct[16 * 4];
   const BwdDir& d = a.d[blockIdx.z];
@@ -280,6 +288,29 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
     bw0[i] = (d.slab_out != nullptr && nt < d.KSt) ? wb[(long)nt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
+  // operands of the gate-gradient math (wave 0): issue their loads before the slab sums so the two
+  // memory round trips overlap
+  constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
+  bool m = true;
+  float carry = 0.f, svv[NSV], cpv = 0.f, cov = 0.f, dcv = 0.f, hpv = 0.f, addAv = 0.f, addBv = 0.f;
+#pragma unroll
+  for (int g = 0; g < NSV; ++g) svv[g] = 0.f;
+  if (wave == 0 && live) {
+    m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+    carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
+    const float* sv = d.saved + (long)b * d.saved_ld + j;
+#pragma unroll
+    for (int g = 0; g < NSV; ++g) svv[g] = sv[(long)g * H];
+    if (d.addA) addAv = d.addA[(long)b * d.addA_ld + j];
+    if (d.addB) addBv = d.addB[(long)b * d.addB_ld + j];
+    if (CELL == CELL_LSTM) {
+      cpv = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+      cov = d.c_out[(long)b * d.c_out_ld + j];
+      dcv = d.dc[(long)b * d.dc_ld + j];
+    }
+    if (CELL == CELL_GRU) hpv = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+  }
+
   // 1. slab reduction, spread over the 4 waves
   float sa = 0.f, sb = 0.f;
   if (live) {
@@ -287,26 +318,22 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
     if (d.slabB) sb = slab_partial(d.slabB, d.QB, d.slabB_qstride, (long)b * d.slabB_ld + d.colB + j, wave);
   }
   red[wave][lane] = sa;
+  red2[wave][lane] = sb;
   __syncthreads();
-  float dh_state = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-  __syncthreads();
-  red[wave][lane] = sb;
-  __syncthreads();
-  float dy = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-  if (d.dropB_rate > 0.f && live) {
-    const AsrRngKey key = asr_rng_key(a.seed[0], d.dropB_stream);
-    dy *= asr_drop_mult(key, (uint32_t)((long)b * d.dropB_ld + d.dropB_off + j), asr_drop_threshold(d.dropB_rate), 1.f / (1.f - d.dropB_rate));
-  }
 
   // 2. gate gradients (wave 0)
   if (wave == 0) {
+    float dh_state = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float dy = red2[0][lane] + red2[1][lane] + red2[2][lane] + red2[3][lane];
+    if (d.dropB_rate > 0.f && live) {
+      const AsrRngKey key = asr_rng_key(a.seed[0], d.dropB_stream);
+      dy *= asr_drop_mult(key, (uint32_t)((long)b * d.dropB_ld + d.dropB_off + j), asr_drop_threshold(d.dropB_rate), 1.f / (1.f - d.dropB_rate));
+    }
     float ds[4] = {0.f, 0.f, 0.f, 0.f};
     float dir = 0.f;
     if (live) {
-      if (d.addA) dh_state += d.addA[(long)b * d.addA_ld + j];
-      if (d.addB) dy += d.addB[(long)b * d.addB_ld + j];
-      const bool m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
-      float carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
+      dh_state += addAv;
+      dy += addBv;
       if (!m) {
         dir = dh_state;                       // state carried unchanged
         if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = carry + dy;
@@ -314,36 +341,31 @@ __global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
       } else {
         const float dh = dh_state + dy + carry;
         if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = 0.f;
-        const float* sv = d.saved + (long)b * d.saved_ld + j;
         if (CELL == CELL_LSTM) {
-          const float ig = sv[0], fg = sv[H], gg = sv[2L * H], og = sv[3L * H];
-          const float cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
-          const float tc = tanhf_(d.c_out[(long)b * d.c_out_ld + j]);
-          float* dcp = d.dc + (long)b * d.dc_ld + j;
-          const float dct = *dcp + dh * og * (1.f - tc * tc);
+          const float ig = svv[0], fg = svv[NSV > 1 ? 1 : 0], gg = svv[NSV > 2 ? 2 : 0], og = svv[NSV > 3 ? 3 : 0];
+          const float tc = tanhf_(cov);
+          const float dct = dcv + dh * og * (1.f - tc * tc);
           ds[0] = dct * gg * ig * (1.f - ig);
-          ds[1] = dct * cp * fg * (1.f - fg);
+          ds[1] = dct * cpv * fg * (1.f - fg);
           ds[2] = dct * ig * (1.f - gg * gg);
           ds[3] = dh * tc * og * (1.f - og);
-          *dcp = dct * fg;
+          d.dc[(long)b * d.dc_ld + j] = dct * fg;
         } else if (CELL == CELL_GRU) {
-          const float z = sv[0], r = sv[H], hh = sv[2L * H], arh = sv[3L * H];
-          const float hp = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+          const float z = svv[0], r = svv[NSV > 1 ? 1 : 0], hh = svv[NSV > 2 ? 2 : 0], arh = svv[NSV > 3 ? 3 : 0];
           const float dahh = dh * (1.f - z) * (1.f - hh * hh);
-          ds[0] = dh * (hp - hh) * z * (1.f - z);
+          ds[0] = dh * (hpv - hh) * z * (1.f - z);
           ds[1] = dahh * arh * r * (1.f - r);
           ds[2] = dahh;
           ds[3] = dahh * r;
           dir = dh * z;
         } else {
-          const float hn = sv[0];
+          const float hn = svv[0];
           ds[0] = dh * (1.f - hn * hn);
         }
       }
-      constexpr int NS = CELL == CELL_RNN ? 1 : 4;
       float* o = d.dslots + (long)b * d.dslots_ld + j;
 #pragma unroll
-      for (int g = 0; g < NS; ++g) o[(long)g * H] = ds[g];
+      for (int g = 0; g < NSV; ++g) o[(long)g * H] = ds[g];
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) dp[bi * 17 + g * 4 + u] = ds[g];

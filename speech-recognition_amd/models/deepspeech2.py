@@ -1,13 +1,278 @@
-"""DeepSpeech2 on MI355X (mirror of speech_recognition/models/deepspeech2.py) - under construction."""
+"""DeepSpeech2 on MI355X (mirror of speech_recognition/models/deepspeech2.py): N x Conv2D ->
+7 x (BiRNN + BatchNormalization) with layer-to-layer state chaining -> frame mask -> Dense(V), trained
+with CTC.  Same constructor (including the upstream spelling ``num_reccurent_layers``), call signature
+and helpers as the reference; all arithmetic in libasr_mi355x.so.
+
+``mask_mode``: the reference's Convolution._audio_mask (deepspeech2.py:74) multiplies the sequence
+length by ``tf.reduce_prod([time_stride, _ in self.strides])`` - the product of the last time stride
+and a Python membership test that is always False, i.e. 0 - so as written every frame is masked and
+the network output collapses to the Dense bias (could not be confirmed by running
+TF).  "intended" (default) uses the product of the time strides; "reference_compat" reproduces the
+all-False mask.
+"""
+from collections import OrderedDict
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+from .. import rng as R
+from ..layers import NG, BiRNN, dense_bwd
+from ..measure import CTCLoss
+from ..params import ParamStore, init_value
+from .las import get_rnn_cls
 from .model_proto import ModelProto
 
 
+class _WS:
+    pass
+
+
 def ctc_loss_only(y_true, y_pred, blank_index, pad_index=0):
-    raise NotImplementedError("CTC kernels are not built yet")
+    """CTCLoss.call (measure.py:32-42) as a plain function: logits [B,T,V], labels [B,L] -> mean loss (device scalar)."""
+    B, T, V = y_pred.shape
+    logits = y_pred.reshape(B * T, V).contiguous().clone()
+    labels = y_true.to(torch.int32).contiguous()
+    ws = torch.empty(ops.ctc_workspace_floats(B, T, labels.shape[1]), device=logits.device)
+    per = torch.empty(B, device=logits.device)
+    stats = torch.zeros(4, device=logits.device)
+    ops.ctc_loss(logits, labels, B, T, blank_index, pad_index, ws, per, stats, write_grad=False)
+    return stats[0]
 
 
 class DeepSpeech2(ModelProto):
     model_checkpoint_path = "model-{epoch}epoch-{val_loss:.4f}loss.ckpt"
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("DeepSpeech2 is not built yet")
+    def __init__(self, num_conv_layers: int, channels: List[int], kernel_sizes: List[List[int]], strides: List[List[int]],
+                 rnn_type: str, num_reccurent_layers: int, hidden_dim: int, dropout: float, recurrent_dropout: float,
+                 vocab_size: int, blank_index: int, pad_index: int = 0, device: str = "cuda", seed: Optional[int] = None,
+                 mask_mode: str = "intended", **kwargs):
+        super().__init__(**kwargs)
+        assert num_conv_layers == len(channels) == len(kernel_sizes) == len(strides), "Convolution parameter number is invalid!"
+        if mask_mode not in ("intended", "reference_compat"):
+            raise ValueError(f"mask_mode: {mask_mode} is invalid!")
+        self.rt = get_rnn_cls(rnn_type)
+        self.channels = list(channels)
+        self.kernel_sizes = [tuple(k) for k in kernel_sizes]
+        self.strides = [tuple(s) for s in strides]
+        self.Lr, self.H, self.V = num_reccurent_layers, hidden_dim, vocab_size
+        self.dropout, self.recurrent_dropout = float(dropout), float(recurrent_dropout)
+        self.blank_index, self.pad_index = blank_index, pad_index
+        self.mask_mode = mask_mode
+        self.device, self.init_seed = device, seed
+        self._ws = {}
+        self._version, self._packed_version = 0, -1
+        self.state = torch.tensor([0, (seed or 0) & 0x7FFFFFFF, 0, 0], dtype=torch.int32, device=device)
+
+    # ------------------------------------------------------------------------------------------ build
+    def conv_out_dims(self, T, Fq):
+        for (kt, kf), (st, sf) in zip(self.kernel_sizes, self.strides):
+            T = (T - kt) // st + 1
+            Fq = (Fq - kf) // sf + 1
+        return T, Fq
+
+    def param_shapes(self, freq_dim, feat_dim):
+        rest, fc, bufs = OrderedDict(), OrderedDict(), OrderedDict()
+        cin = feat_dim
+        for i, (ch, (kt, kf)) in enumerate(zip(self.channels, self.kernel_sizes)):
+            rest[f"convolution/conv_layers/{i}/kernel"] = (kt, kf, cin, ch)
+            rest[f"convolution/conv_layers/{i}/bias"] = (ch,)
+            cin = ch
+        _, Fo = self.conv_out_dims(10 ** 6, freq_dim)
+        din = Fo * cin
+        for i in range(self.Lr):
+            rest.update(BiRNN.param_shapes(f"recurrent/rnn_layers/{i}/", self.rt, din, self.H))
+            rest[f"recurrent/batch_norm/{i}/gamma"] = (2 * self.H,)
+            rest[f"recurrent/batch_norm/{i}/beta"] = (2 * self.H,)
+            bufs[f"recurrent/batch_norm/{i}/moving_mean"] = (2 * self.H,)
+            bufs[f"recurrent/batch_norm/{i}/moving_variance"] = (2 * self.H,)
+            din = 2 * self.H
+        fc["fully_connected/kernel"] = (2 * self.H, self.V)
+        fc["fully_connected/bias"] = (self.V,)
+        return fc, rest, bufs
+
+    def build(self, frequency_dim: int, feature_dim: int):
+        self.F, self.C = frequency_dim, feature_dim
+        fc, rest, bufs = self.param_shapes(frequency_dim, feature_dim)
+        shapes = OrderedDict(list(fc.items()) + list(rest.items()))
+        self.store = ParamStore(shapes, [list(fc), list(rest)], self.device)
+        gen = torch.Generator().manual_seed(self.init_seed if self.init_seed is not None else 0)
+        self.store.load({n: init_value(n, s, gen, self.rt) for n, s in shapes.items()})
+        self.buffers = {n: init_value(n, s, gen).to(self.device) for n, s in bufs.items()}
+        _, Fo = self.conv_out_dims(10 ** 6, frequency_dim)
+        self.D0 = Fo * self.channels[-1]
+        self.layers = []
+        din = self.D0
+        for i in range(self.Lr):
+            self.layers.append(BiRNN(self.store, f"recurrent/rnn_layers/{i}/", self.rt, din, self.H, self.dropout,
+                                     R.STREAM_ENC_IN + 2 * i, self.device))
+            din = 2 * self.H
+        self.built = True
+        self.weights_changed()
+        return self
+
+    def _ensure_built(self, freq_dim, feat_dim):
+        if not self.built:
+            self.build(freq_dim, feat_dim)
+        elif (freq_dim, feat_dim) != (self.F, self.C):
+            raise ValueError(f"model was built for [T,{self.F},{self.C}] features, got [T,{freq_dim},{feat_dim}]")
+
+    def weights_changed(self):
+        self._version += 1
+
+    def pack_weights(self):
+        for l in self.layers:
+            l.pack()
+        self._packed_version = self._version
+
+    @property
+    def seed(self):
+        return self.state[1:2]
+
+    def draw_teacher_forcing(self):
+        return True
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _workspace(self, B, T, L=1):
+        key = (B, T, L)
+        if key in self._ws:
+            return self._ws[key]
+        dev, H, V = self.device, self.H, self.V
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        ws = _WS()
+        ws.B, ws.T, ws.L = B, T, L
+        ws.conv = []
+        t, fq, cin = T, self.F, self.C
+        for ch, (kt, kf), (st, sf) in zip(self.channels, self.kernel_sizes, self.strides):
+            if t < kt or fq < kf:
+                raise ValueError(f"input [{T},{self.F}] is too small for the convolution stack")
+            t, fq = (t - kt) // st + 1, (fq - kf) // sf + 1
+            ws.conv.append(f(B, t, fq, ch))
+        ws.T2 = T2 = t
+        ws.mask = torch.zeros(B, T2, dtype=torch.uint8, device=dev)
+        ws.layers = [dict(rnn=l.alloc(B, T2, dev), a=f(B * T2, 2 * H), mean=f(2 * H), rstd=f(2 * H)) for l in self.layers]
+        ws.bn_ws = torch.empty(4 * H, dtype=torch.float64, device=dev)
+        ws.xm, ws.logits = f(B * T2, 2 * H), f(B * T2, V)
+        ws.stats = torch.zeros(4, device=dev)
+        ws.per_sample = f(B)
+        ws.ctc_ws = f(ops.ctc_workspace_floats(B, T2, L))
+        # backward
+        ws.dxm, ws.dy = f(B * T2, 2 * H), f(B, T2, 2 * H)
+        ws.dx = [f(B * T2, 2 * H), f(B * T2, 2 * H)]
+        ws.dx0 = f(B, T2, self.D0)
+        ws.dconv = [f(*c.shape) for c in ws.conv[:-1]]
+        ws.dc = [f(B, H), f(B, H)]
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward_ws(self, ws, audio, training, use_teacher_forcing=True):
+        """DeepSpeech2.call (deepspeech2.py:174-178)."""
+        if training and self.recurrent_dropout > 0:
+            raise NotImplementedError("recurrent_dropout > 0 is not supported (0.0 in every shipped config)")
+        if self._packed_version != self._version:
+            self.pack_weights()
+        p, B, T2, H = self.store.p, ws.B, ws.T2, self.H
+        ws.training = training
+        # Convolution._audio_mask (deepspeech2.py:68-78)
+        if self.mask_mode == "intended":
+            group = 1
+            for st, _ in self.strides:
+                group *= st
+            ops.frame_mask(audio, group, T2, ws.mask)
+        x = audio
+        for i, y in enumerate(ws.conv):
+            ops.conv2d_fwd(x, p[f"convolution/conv_layers/{i}/kernel"], p[f"convolution/conv_layers/{i}/bias"], self.strides[i], y)
+            x = y
+        x3 = x.view(B, T2, self.D0)
+        states = None
+        for i, (l, lw) in enumerate(zip(self.layers, ws.layers)):
+            y = l.forward(lw["rnn"], x3, ws.mask, states, training, self.seed)
+            states = l.final_states(lw["rnn"])
+            bn = f"recurrent/batch_norm/{i}/"
+            ops.bn_fwd(y.view(B * T2, 2 * H), p[bn + "gamma"], p[bn + "beta"], lw["a"], lw["mean"], lw["rstd"],
+                       self.buffers[bn + "moving_mean"], self.buffers[bn + "moving_variance"], ws.bn_ws, relu=False, training=training)
+            x3 = lw["a"].view(B, T2, 2 * H)
+        ops.mask_rows(ws.layers[-1]["a"], ws.mask.view(-1), ws.xm)                     # deepspeech2.py:176
+        ops.gemm(ws.xm, p["fully_connected/kernel"], ws.logits, bias=p["fully_connected/bias"])
+        return ws.logits
+
+    def forward(self, audio, training=False):
+        ops._dev(audio, name="audio")
+        self._ensure_built(audio.shape[2], audio.shape[3])
+        ws = self._workspace(audio.shape[0], audio.shape[1])
+        self.forward_ws(ws, audio.contiguous(), training)
+        return ws.logits.view(ws.B, ws.T2, self.V)
+
+    def call(self, audio_input, training: bool = False):
+        return self.forward(audio_input, bool(training))
+
+    # ------------------------------------------------------------------------------------------ training hooks
+    def train_workspace(self, B, T, L):
+        return self._workspace(B, T, L), torch.empty(B, L, dtype=torch.int32, device=self.device)
+
+    def set_targets(self, ws, tokens, labels):
+        """make_example (deepspeech2.py:192-202): the full token row (BOS/EOS kept) is the CTC label."""
+        labels.copy_(tokens)
+
+    def loss_and_grad(self, ws, labels, grad_scale=1.0):
+        """CTCLoss (measure.py:24-42) over ws.logits (overwritten with its gradient); ws.stats[0] <- loss."""
+        ops.fill(ws.stats, 0.0)
+        ops.ctc_loss(ws.logits, labels, ws.B, ws.T2, self.blank_index, self.pad_index, ws.ctc_ws, ws.per_sample, ws.stats, True, grad_scale)
+
+    def backward_segments(self, ws, audio):
+        return [lambda: self.backward_head(ws), lambda: self.backward_body(ws, audio)]
+
+    def backward_ws(self, ws, audio):
+        for seg in self.backward_segments(ws, audio):
+            seg()
+
+    def backward_head(self, ws):
+        assert ws.training, "backward needs a training-mode forward"
+        p, g = self.store.p, self.store.g
+        dense_bwd(ws.xm, p["fully_connected/kernel"], ws.logits, g["fully_connected/kernel"], g["fully_connected/bias"], ws.dxm)
+        ops.mask_rows(ws.dxm, ws.mask.view(-1), ws.dxm)
+
+    def backward_body(self, ws, audio):
+        p, g = self.store.p, self.store.g
+        B, T2, H = ws.B, ws.T2, self.H
+        da = ws.dxm
+        dfin = [None, None]
+        if self.rt == "lstm":
+            ops.fill(ws.dc[0], 0.0)
+            ops.fill(ws.dc[1], 0.0)
+        for i in range(self.Lr - 1, -1, -1):
+            l, lw = self.layers[i], ws.layers[i]
+            bn = f"recurrent/batch_norm/{i}/"
+            y2 = lw["rnn"]["y"].view(B * T2, 2 * H)
+            ops.bn_bwd(y2, None, da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dy.view(B * T2, 2 * H), g[bn + "gamma"], g[bn + "beta"],
+                       ws.bn_ws, relu=False)
+            dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * H)
+            dfin = l.backward(lw["rnn"], ws.dy, dfin, ws.dc, dx)
+            da = dx.view(B * T2, -1)
+        # convolutions (deepspeech2.py:57-59), no dropout / activation in between
+        dy = ws.dx0.view(ws.conv[-1].shape)
+        for i in range(len(ws.conv) - 1, -1, -1):
+            x = audio if i == 0 else ws.conv[i - 1]
+            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{i}/kernel"], self.strides[i])
+            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{i}/bias"])
+            if i > 0:
+                ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{i}/kernel"], ws.dconv[i - 1], self.strides[i])
+                dy = ws.dconv[i - 1]
+
+    # ------------------------------------------------------------------------------------------ reference API
+    def get_loss_fn(self):
+        return CTCLoss(self.blank_index, self.pad_index)
+
+    def get_metrics(self):
+        return []
+
+    @staticmethod
+    def get_batching_shape(audio_pad_length: Optional[int], token_pad_length: Optional[int], frequency_dim: int,
+                           feature_dim: int):
+        return ([audio_pad_length, frequency_dim, feature_dim], [token_pad_length])
+
+    @staticmethod
+    def make_example(audio, tokens):
+        """deepspeech2.py:192-202: the input is used directly as the example."""
+        return audio, tokens

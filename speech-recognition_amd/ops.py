@@ -413,3 +413,22 @@ def adam_step(params, grads, m, v, state, sched, beta1=0.9, beta2=0.999, eps=1e-
 
 def advance_state(state):
     check(lib().asr_advance_state(_p(state), _stream()))
+
+
+def ctc_workspace_floats(B, T, L):
+    return int(lib().asr_ctc_workspace_floats(B, T, L))
+
+
+def ctc_loss(logits2d, labels, B, T, blank, pad, ws, per_sample, stats, write_grad=True, grad_scale=1.0):
+    """logits2d [B*T, V] (overwritten with the gradient when write_grad), labels i32 [B, L]."""
+    _dev(labels, torch.int32, "labels")
+    V, L = logits2d.shape[1], labels.shape[1]
+    assert labels.is_contiguous() and logits2d.shape[0] == B * T
+    check(lib().asr_ctc_loss(_p(logits2d), logits2d.stride(0), _p(labels), B, T, V, L, int(blank), int(pad), _p(ws), _p(per_sample),
+                             _p(stats), int(write_grad), float(grad_scale), _stream()))
+
+
+def mask_rows(x2d, mask, out2d):
+    """out[r,:] = x[r,:] * mask[r]; mask uint8 [R] contiguous."""
+    check(lib().asr_mask_rows(_p(x2d), x2d.stride(0), _p(mask), x2d.shape[0], x2d.shape[1], _p(out2d), out2d.stride(0), _stream()))
+    return out2d
