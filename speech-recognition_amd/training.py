@@ -21,6 +21,43 @@ from . import ops
 from . import rng as R
 
 
+class GradientExchange:
+    """Data-parallel gradient exchange (the implicit all-reduce of tf.distribute.MirroredStrategy,
+    utils.py:148-149): sums the buckets of a flat gradient buffer across the ranks of a process group.
+    On GPUs the reduction of bucket k is issued on a side stream as soon as backward segment k+1 has
+    been enqueued, so RCCL traffic over xGMI overlaps the remaining backward kernels; on CPU tensors
+    (gloo; used by the unit tests) it runs synchronously.  Replicas are expected to have scaled their
+    loss gradient by 1/world_size, so SUM yields the replica mean."""
+
+    def __init__(self, world_size: int, group=None, compute_stream=None):
+        self.world, self.group, self.stream = world_size, group, compute_stream
+        self.comm_stream = torch.cuda.Stream() if (compute_stream is not None and world_size > 1) else None
+        self._pending = []
+
+    def reduce_async(self, bucket: torch.Tensor):
+        """Start summing `bucket` (a contiguous 1-D view) across ranks."""
+        if self.world <= 1 or bucket is None or bucket.numel() == 0:
+            return
+        import torch.distributed as dist
+        if self.comm_stream is None:                      # CPU / gloo path
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record(self.stream)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        self._pending.append(done)
+
+    def wait(self):
+        """Make the compute stream wait for every reduction started since the last wait()."""
+        for ev in self._pending:
+            self.stream.wait_event(ev)
+        self._pending = []
+
+
 class TrainStep:
     def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
                  beta1=0.9, beta2=0.999, eps=1e-7):
@@ -35,7 +72,7 @@ class TrainStep:
         self.group = getattr(strategy, "group", None)
         self._shapes: Dict[tuple, dict] = {}
         self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.exchange = GradientExchange(self.world, self.group, self.stream)
         self.iterations = 0
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -115,38 +152,22 @@ class TrainStep:
             c["tokens"].copy_(tokens, non_blocking=True)
             m.set_targets(c["ws"], c["tokens"], c["labels"])   # layout copies of the token rows (not captured)
             segs = self._segments(c, teacher)
-            handles = []
             buckets = m.store.bucket_views()
+            assert len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
             for k, fn in enumerate(segs):
                 self._run_segment(c, teacher, k, fn)
-                if self.world > 1 and k >= 1:
-                    handles.append(self._allreduce_async(buckets[k - 1] if k - 1 < len(buckets) else None))
-            for h in handles:
-                if h is not None:
-                    self.stream.wait_event(h)
+                if k >= 1:
+                    self.exchange.reduce_async(buckets[k - 1])
+            self.exchange.wait()
             self._run_segment(c, teacher, "update", self._update)
         m.weights_changed()
         self.iterations += 1
         return c["ws"]
 
-    def _allreduce_async(self, bucket):
-        """Sum one gradient bucket across ranks on the communication stream; returns an event."""
-        if bucket is None:
-            return None
-        import torch.distributed as dist
-        ready = torch.cuda.Event()
-        ready.record(self.stream)
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ready)
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
-            done = torch.cuda.Event()
-            done.record(self.comm_stream)
-        return done
-
     def synchronize(self):
         self.stream.synchronize()
-        if self.comm_stream is not None:
-            self.comm_stream.synchronize()
+        if self.exchange.comm_stream is not None:
+            self.exchange.comm_stream.synchronize()
 
     def read_stats(self, ws):
         """Host copy of [loss, #correct, #kept] (synchronises)."""
