@@ -1,78 +1,129 @@
 // asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h).
 #include "gemm_core.h"
 
-template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void gemm_kernel(PlainLoader al, PlainLoader bl, GemmEpilogue ep, int K,
-                                                   long sAz, long sBz, long sCz, long sAscale, int tiles_m,
-                                                   int split_k, int k_chunk) {
+// Tile order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an
+// XCD's L2 - a speed assumption only), so the linear id is first remapped to p = (position of b inside
+// its XCD's own sequence, XCD-major): every XCD then owns one contiguous range of p.  p walks the
+// tiles of the SMALLER operand fastest, so the concurrently resident blocks of an XCD share the tile
+// of the larger operand (read from HBM once) while the smaller operand stays L2 resident.
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int walk_n, int* bm, int* bn) {
+  const int total = tiles_m * tiles_n;
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const int p = xcd * (total >> 3) + min(xcd, total & 7) + idx;   // bijection on [0, total)
+  if (walk_n) { *bm = p / tiles_n; *bn = p - *bm * tiles_n; }
+  else { *bn = p / tiles_m; *bm = p - *bn * tiles_m; }
+}
+
+template <class AL, class BL, int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void gemm_kernel(AL al, BL bl, GemmEpilogue ep, int K, long sAz, long sBz, long sCz, long sAscale,
+                                                   int tiles_m, int tiles_n, int walk_n, int split_k, int k_chunk) {
   using T = GemmTile<TA, TB, BM, BN, WAVES_M, WAVES_N>;
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
   const int z = blockIdx.z / split_k, zs = blockIdx.z % split_k;
-  al.p += (long)z * sAz;
-  bl.p += (long)z * sBz;
+  al.offset_z((long)z * sAz, (long)z * sAscale);
+  bl.offset_z((long)z * sBz, 0);
   ep.C += (long)z * sCz;
-  if (al.scale != nullptr) al.scale += (long)z * sAscale;
   if ((z != 0 && sCz == 0) || zs != 0) ep.bias = nullptr;  // split-K: bias is added once
   const int kbeg = zs * k_chunk, kend = min(K, kbeg + k_chunk);
   if (kbeg >= K && !(K == 0 && zs == 0)) return;
-  // consecutive blocks walk M first: neighbours share the same B (weight) tile in L2
-  const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
+  int bm, bn;
+  tile_of_block(tiles_m, tiles_n, walk_n, &bm, &bn);
   T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
-template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
-static void launch_cfg(const PlainLoader& al, const PlainLoader& bl, const GemmEpilogue& ep, const asr_gemm_desc* d,
-                       hipStream_t st) {
+struct GemmPlan {
+  const asr_gemm_desc* d;
+  const float* A; const float* B;
+  int a_rows, a_cols, b_rows, b_cols;
+  GemmEpilogue ep;
+  hipStream_t st;
+};
+
+template <class AL, class BL, int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
+static void launch_cfg(const GemmPlan& g, const AL& al, const BL& bl) {
+  const asr_gemm_desc* d = g.d;
   const int tm = asr_cdiv(d->M, BM), tn = asr_cdiv(d->N, BN);
   const int sk = d->split_k > 1 ? d->split_k : 1;
-  const int k_chunk = asr_cdiv(asr_cdiv(d->K, sk), GEMM_BK) * GEMM_BK;  // BK-aligned partitions
+  int k_chunk = asr_cdiv(asr_cdiv(d->K, sk), GEMM_BK) * GEMM_BK;  // BK-aligned partitions
+  if (k_chunk <= 0) k_chunk = GEMM_BK;
+  // the operand with fewer bytes stays L2 resident; walk its tiles fastest
+  const int walk_n = ((long)d->K * d->N <= (long)d->M * d->K) ? 1 : 0;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * sk));
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, st, al, bl, ep, d->K,
-                     d->stride_a, d->stride_b, d->stride_c, d->stride_a_scale, tm, sk, k_chunk > 0 ? k_chunk : GEMM_BK);
+  hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
+                     d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
 }
 
-template <int TA, int TB>
-static void launch_t(const PlainLoader& al, const PlainLoader& bl, const GemmEpilogue& ep, const asr_gemm_desc* d,
-                     hipStream_t st) {
-  const long big = (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 128) * d->batch * (d->split_k > 1 ? d->split_k : 1);
-  if (d->N <= 32) launch_cfg<TA, TB, 256, 32, 4, 1>(al, bl, ep, d, st);
-  else if (d->M <= 32) launch_cfg<TA, TB, 32, 256, 1, 4>(al, bl, ep, d, st);
-  else if (big >= 192) launch_cfg<TA, TB, 128, 128, 2, 2>(al, bl, ep, d, st);
-  else launch_cfg<TA, TB, 64, 64, 2, 2>(al, bl, ep, d, st);
+template <class AL, class BL, int TA, int TB>
+static void launch_t(const GemmPlan& g, const AL& al, const BL& bl) {
+  const asr_gemm_desc* d = g.d;
+  if (d->N <= 32) { launch_cfg<AL, BL, TA, TB, 256, 32, 4, 1>(g, al, bl); return; }
+  if (d->M <= 32) { launch_cfg<AL, BL, TA, TB, 32, 256, 1, 4>(g, al, bl); return; }
+  // pick the tile by a wave-quantisation model: workgroups are dealt over 256 CUs in rounds of
+  // (up to) 3 resident per CU; bigger tiles have the higher per-flop efficiency (less LDS staging)
+  const long z = (long)d->batch * (d->split_k > 1 ? d->split_k : 1);
+  auto score = [&](int bm, int bn, double tile_eff) {
+    const long wgs = (long)asr_cdiv(d->M, bm) * asr_cdiv(d->N, bn) * z;
+    const long rounds = (wgs + 255) / 256;                 // per-CU sequential tiles (at equal sharing)
+    const double useful = (double)d->M * d->N * z;         // useful output elements
+    return tile_eff * useful / ((double)rounds * 256 * bm * bn);
+  };
+  const double s128 = score(128, 128, 1.0), s12864 = score(128, 64, 0.92), s64128 = score(64, 128, 0.92), s64 = score(64, 64, 0.80);
+  if (s128 >= s12864 && s128 >= s64128 && s128 >= s64) launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl);
+  else if (s12864 >= s64128 && s12864 >= s64) launch_cfg<AL, BL, TA, TB, 128, 64, 2, 2>(g, al, bl);
+  else if (s64128 >= s64) launch_cfg<AL, BL, TA, TB, 64, 128, 2, 2>(g, al, bl);
+  else launch_cfg<AL, BL, TA, TB, 64, 64, 2, 2>(g, al, bl);
 }
 
-static inline int aligned16(const void* p, long ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
+template <class AL, class BL>
+static void launch_l(const GemmPlan& g, const AL& al, const BL& bl) {
+  const asr_gemm_desc* d = g.d;
+  if (!d->trans_a && !d->trans_b) launch_t<AL, BL, 0, 0>(g, al, bl);
+  else if (!d->trans_a && d->trans_b) launch_t<AL, BL, 0, 1>(g, al, bl);
+  else if (d->trans_a && !d->trans_b) launch_t<AL, BL, 1, 0>(g, al, bl);
+  else launch_t<AL, BL, 1, 1>(g, al, bl);
+}
+
+static inline bool aligned16(const void* p, long ld, long stride) {
+  return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (stride % 4 == 0);
+}
 
 extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream) {
   ASR_CHECK(d && A && B && C, ASR_ERR_ARG, "asr_gemm_f32: null argument");
   ASR_CHECK(d->M > 0 && d->N > 0 && d->K >= 0 && d->batch >= 1, ASR_ERR_SHAPE, "asr_gemm_f32: bad M/N/K/batch %d %d %d %d",
             d->M, d->N, d->K, d->batch);
-  const int a_rows = d->trans_a ? d->K : d->M, a_cols = d->trans_a ? d->M : d->K;
-  const int b_rows = d->trans_b ? d->N : d->K, b_cols = d->trans_b ? d->K : d->N;
-  ASR_CHECK(d->lda >= a_cols && d->ldb >= b_cols && d->ldc >= d->N, ASR_ERR_SHAPE,
+  GemmPlan g;
+  g.d = d; g.A = A; g.B = B; g.st = (hipStream_t)stream;
+  g.a_rows = d->trans_a ? d->K : d->M; g.a_cols = d->trans_a ? d->M : d->K;
+  g.b_rows = d->trans_b ? d->N : d->K; g.b_cols = d->trans_b ? d->K : d->N;
+  ASR_CHECK(d->lda >= g.a_cols && d->ldb >= g.b_cols && d->ldc >= d->N, ASR_ERR_SHAPE,
             "asr_gemm_f32: leading dimension smaller than row length (lda %ld ldb %ld ldc %ld)", d->lda, d->ldb, d->ldc);
   ASR_CHECK((long)d->batch * (d->split_k > 1 ? d->split_k : 1) <= 65535, ASR_ERR_SHAPE, "asr_gemm_f32: batch*split_k > 65535");
   ASR_CHECK(!(d->split_k > 1 && !d->accumulate), ASR_ERR_ARG, "asr_gemm_f32: split_k > 1 accumulates atomically: set accumulate and pre-zero C");
   ASR_CHECK(!(d->a_scale && d->a_rpg <= 0) && !(d->c_scale && d->c_rpg <= 0), ASR_ERR_ARG,
             "asr_gemm_f32: group scale needs rows-per-group > 0");
-  hipStream_t st = (hipStream_t)stream;
-  PlainLoader al{A, d->lda, a_rows, a_cols, aligned16(A, d->lda) && (d->stride_a % 4 == 0), d->a_scale, d->a_rpg};
-  PlainLoader bl{B, d->ldb, b_rows, b_cols, aligned16(B, d->ldb) && (d->stride_b % 4 == 0), nullptr, 1};
   int mode = d->accumulate ? 1 : 0;
   if (d->batch > 1 && d->stride_c == 0) {
     ASR_CHECK(d->accumulate, ASR_ERR_ARG, "asr_gemm_f32: batch>1 with stride_c==0 (split-K) requires accumulate=1");
     mode = 2;
   }
   if (d->accumulate == 2 || d->split_k > 1) mode = 2;
-  GemmEpilogue ep{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
-  if (d->K == 0) {
-    // nothing to accumulate; for store mode the result is bias only - still run with K=0 (loop skipped)
+  g.ep = GemmEpilogue{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
+
+  const bool a_fast = d->K > 0 && aligned16(A, d->lda, d->stride_a) && g.a_cols % 4 == 0 && g.a_cols >= 4;
+  const bool b_fast = d->K > 0 && aligned16(B, d->ldb, d->stride_b) && g.b_cols % 4 == 0 && g.b_cols >= 4;
+  const bool s_fast = d->a_scale && (((uintptr_t)d->a_scale & 15) == 0) && d->stride_a_scale % 4 == 0 &&
+                      (long)g.a_rows * d->a_rpg < 4294967296L;
+  if (a_fast && b_fast && !d->a_scale) {
+    launch_l(g, FastLoader{A, d->lda, g.a_rows, g.a_cols}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
+  } else if (a_fast && b_fast && s_fast) {
+    const uint32_t magic = (uint32_t)((4294967296ULL + (uint64_t)d->a_rpg - 1) / (uint64_t)d->a_rpg);
+    launch_l(g, FastScaledLoader{A, d->lda, g.a_rows, g.a_cols, d->a_scale, magic}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
+  } else {
+    PlainLoader al{A, d->lda, g.a_rows, g.a_cols, aligned16(A, d->lda, d->stride_a), d->a_scale, d->a_rpg};
+    PlainLoader bl{B, d->ldb, g.b_rows, g.b_cols, aligned16(B, d->ldb, d->stride_b), nullptr, 1};
+    launch_l(g, al, bl);
   }
-  if (!d->trans_a && !d->trans_b) launch_t<0, 0>(al, bl, ep, d, st);
-  else if (!d->trans_a && d->trans_b) launch_t<0, 1>(al, bl, ep, d, st);
-  else if (d->trans_a && !d->trans_b) launch_t<1, 0>(al, bl, ep, d, st);
-  else launch_t<1, 1>(al, bl, ep, d, st);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -16,7 +16,39 @@
 #define GEMM_BK 32
 
 // ---- loader policies: fetch4(r, c, v) reads stored[r][c..c+3] with zero fill outside [R, Cc)
+// FastLoader: 16-byte aligned rows, Cc % 4 == 0 - branch-free (clamped address + select).
+struct FastLoader {
+  const float* p;
+  long ld;
+  int R, Cc;
+  __device__ __forceinline__ void offset_z(long da, long) { p += da; }
+  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
+    const int rr = min(r, R - 1), cc = min(c, Cc - 4);
+    const float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + cc);
+    const bool ok = (r < R) && (c < Cc);
+    v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
+  }
+};
+// FastScaledLoader: FastLoader times a row-group table scale[(r / rpg)][Cc] (Keras RNN input dropout);
+// the division is a multiply-high by magic = ceil(2^32 / rpg) (exact for r * rpg < 2^32, host checked).
+struct FastScaledLoader {
+  const float* p;
+  long ld;
+  int R, Cc;
+  const float* scale;
+  uint32_t magic;
+  __device__ __forceinline__ void offset_z(long da, long ds) { p += da; scale += ds; }
+  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
+    const int rr = min(r, R - 1), cc = min(c, Cc - 4);
+    const float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + cc);
+    const float4 s = *reinterpret_cast<const float4*>(scale + (long)__umulhi((uint32_t)rr, magic) * Cc + cc);
+    const bool ok = (r < R) && (c < Cc);
+    v[0] = ok ? t.x * s.x : 0.f; v[1] = ok ? t.y * s.y : 0.f; v[2] = ok ? t.z * s.z : 0.f; v[3] = ok ? t.w * s.w : 0.f;
+  }
+};
+// PlainLoader: any alignment / size, optional scale (slow path for odd shapes).
 struct PlainLoader {
+  __device__ __forceinline__ void offset_z(long da, long ds) { p += da; if (scale != nullptr) scale += ds; }
   const float* p;
   long ld;
   int R, Cc;       // stored rows / cols
@@ -73,6 +105,14 @@ struct GemmEpilogue {
 
 // TA: 0 -> A stored [M][K] (k contiguous); 1 -> A stored [K][M] (m contiguous). Same for TB with
 // 0 -> B stored [K][N] (n contiguous); 1 -> B stored [N][K] (k contiguous).
+//
+// K pairing: within every group of 8 consecutive k, MFMA step e (0..3) multiplies k = 8g+e (lanes
+// 0-31) and k = 8g+4+e (lanes 32-63) - any pairing is valid as long as A and B agree, and this one
+// lets a k-contiguous operand be read from LDS as ONE ds_read_b128 per lane per 8 k (its 4 values
+// are the lane's operands of the 4 steps).  LDS images:
+//   k-contiguous operand : float4 granules [k/4][mn ^ (k/4)]  - b128 stores from the coalesced global
+//                          load mapping and b128 reads, both conflict-free through the XOR swizzle
+//   mn-contiguous operand: [k][mn] floats, b128 stores, b32 reads (consecutive lanes -> consecutive mn)
 template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
 struct GemmTile {
   static constexpr int BK = GEMM_BK;
@@ -80,10 +120,8 @@ struct GemmTile {
   static constexpr int MI = WM / 32, NI = WN / 32;
   static constexpr int A_KC = (TA == 0);  // A has k contiguous
   static constexpr int B_KC = (TB == 1);  // B has k contiguous
-  static constexpr int A_LD = A_KC ? (BK + 1) : BM;
-  static constexpr int B_LD = B_KC ? (BK + 1) : BN;
-  static constexpr int A_ELEMS = A_KC ? BM * (BK + 1) : BK * BM;
-  static constexpr int B_ELEMS = B_KC ? BN * (BK + 1) : BK * BN;
+  static constexpr int A_ELEMS = BM * BK;
+  static constexpr int B_ELEMS = BN * BK;
   static constexpr int A_V4 = BM * BK / 4 / 256;  // float4 fetches per thread per tile
   static constexpr int B_V4 = BN * BK / 4 / 256;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -102,6 +140,8 @@ struct GemmTile {
       for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4* As4 = reinterpret_cast<float4*>(As);
+    float4* Bs4 = reinterpret_cast<float4*>(Bs);
 
     auto gload = [&](int k0) {
 #pragma unroll
@@ -121,63 +161,66 @@ struct GemmTile {
 #pragma unroll
       for (int i = 0; i < A_V4; ++i) {
         const int f = tid + i * 256;
-        if (A_KC) {
-          const int r = f / (BK / 4), q = f % (BK / 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) As[r * A_LD + 4 * q + e] = ra[i][e];
-        } else {
-          const int r = f / (BM / 4), q = f % (BM / 4);
-          *reinterpret_cast<float4*>(&As[r * A_LD + 4 * q]) = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
-        }
+        const float4 v = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+        if (A_KC) { const int r = f / (BK / 4), q = f % (BK / 4); As4[q * BM + (r ^ q)] = v; }
+        else      { const int r = f / (BM / 4), q = f % (BM / 4); As4[r * (BM / 4) + q] = v; }
       }
 #pragma unroll
       for (int i = 0; i < B_V4; ++i) {
         const int f = tid + i * 256;
-        if (B_KC) {
-          const int r = f / (BK / 4), q = f % (BK / 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) Bs[r * B_LD + 4 * q + e] = rb[i][e];
-        } else {
-          const int r = f / (BN / 4), q = f % (BN / 4);
-          *reinterpret_cast<float4*>(&Bs[r * B_LD + 4 * q]) = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
-        }
+        const float4 v = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+        if (B_KC) { const int r = f / (BK / 4), q = f % (BK / 4); Bs4[q * BN + (r ^ q)] = v; }
+        else      { const int r = f / (BN / 4), q = f % (BN / 4); Bs4[r * (BN / 4) + q] = v; }
       }
     };
 
     // K range [kbeg, kend): kbeg is a multiple of BK (split-K partitions are BK aligned); the loaders
-    // zero-fill past their own extent, and kend < extent is enforced by clamping the loop count only
-    // when the partition ends on a BK boundary (the host guarantees that for every partition but the last)
+    // zero-fill past their own extent
     const int nk = (kend - kbeg + BK - 1) / BK;
+    const int l31 = lane & 31, lh = lane >> 5;
     gload(kbeg);
     for (int kt = 0; kt < nk; ++kt) {
       lstore();
       __syncthreads();
       if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
-      const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        const int k = kk + lh;
-        float a[MI], b[NI];
+      for (int g = 0; g < BK / 8; ++g) {
+        float a[MI][4], b[NI][4];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int m = wm * WM + i * 32 + l31;
-          a[i] = A_KC ? As[m * A_LD + k] : As[k * A_LD + m];
+          if (A_KC) {
+            const int q = 2 * g + lh;
+            const float4 t = As4[q * BM + (m ^ q)];
+            a[i][0] = t.x; a[i][1] = t.y; a[i][2] = t.z; a[i][3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[i][e] = As[(8 * g + 4 * lh + e) * BM + m];
+          }
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int n = wn * WN + j * 32 + l31;
-          b[j] = B_KC ? Bs[n * B_LD + k] : Bs[k * B_LD + n];
+          if (B_KC) {
+            const int q = 2 * g + lh;
+            const float4 t = Bs4[q * BN + (n ^ q)];
+            b[j][0] = t.x; b[j][1] = t.y; b[j][2] = t.z; b[j][3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * g + 4 * lh + e) * BN + n];
+          }
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
     // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -20,8 +20,9 @@ NS = {"lstm": 4, "gru": 4, "rnn": 1}   # columns saved per unit by the cell kern
 
 def auto_split_k(M, N, K):
     """K partitions for a weight-gradient GEMM (tiny M x N, huge K) so that ~1k workgroups run."""
+    # ~2 workgroups per CU: more partitions only add atomic traffic (every partition adds M*N floats)
     tiles = math.ceil(M / 128) * math.ceil(N / 128) if M > 64 and N > 64 else math.ceil(M / 64) * math.ceil(N / 64)
-    s = max(1, min(768 // max(tiles, 1), K // 128))
+    s = max(1, min(512 // max(tiles, 1), K // 256))
     return max(1, s)
 
 
