@@ -208,11 +208,9 @@ int asr_mask_rows(const float* x, long ldx, const uint8_t* mask, int R, int C, f
 
 typedef struct asr_rnn_geom {
   int Q;                       /* unit groups of 4: ceil(H / 4)                                   */
-  int KSt;                     /* packed K steps: sum over segments of ceil(K_i / 4)              */
-  int NT;                      /* slab column tiles: ceil(4 KSt / 16)                             */
-  int ks0[ASR_RNN_MAXSEG];     /* first K step of each segment; its first packed column = 4 ks0   */
-  long wp_floats, wpb_floats;  /* sizes of the two packed weight images                           */
-  int slab_ld;                 /* slab row length = 16 NT                                         */
+  int KSt;                     /* packed 16-wide K blocks: sum over segments of ceil(K_i / 16)    */
+  int ks0[ASR_RNN_MAXSEG];     /* first block of each segment                                     */
+  long wp_floats;              /* size of the packed forward weight image                         */
 } asr_rnn_geom;
 int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr_rnn_geom* g);
 
@@ -220,7 +218,7 @@ int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr_rnn_geom* 
  * [K_i, G*H] Keras layout, row stride ldw[i]; is_rec marks the recurrent segment) into MFMA
  * fragment order.  Must be re-run whenever the weights change (once per optimizer step). */
 int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const long* ldw, const int* K, const int* is_rec,
-                 float* Wp, float* Wpb, void* stream);
+                 float* Wp, void* stream);
 
 /* One cell step for one direction; row b of every matrix is at ptr + b * ld. */
 typedef struct asr_rnn_step_fwd {
@@ -248,17 +246,25 @@ typedef struct asr_rnn_step_fwd {
 int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fwd* steps, const uint32_t* seed,
                      void* stream);
 
+/* Backward of one cell step.  The gradient handed from step to step is ds, the gradient wrt the gate
+ * sums ([B, NS*H], written over the saved activations).  A source describes one consumer of this
+ * cell's h (srcA, -> state gradient) or emitted output (srcB, -> output gradient, optionally through
+ * that consumer's input dropout): dh[b, j] = sum_c D[b, d_col0 + c] * W[j * ldw + w_col0 + c] over the
+ * column segments (W rows = Keras kernel rows: recurrent kernel rows are units, input kernel rows are
+ * input features).  out != NULL selects the linear mode: out = sum_A + addA + direct + sum_B + addB. */
+typedef struct asr_rnn_back_src {
+  const float* D; long ldd;                 /* consumer's ds rows (NULL: source unused)             */
+  const float* W; long ldw;
+  int nseg; int d_col0[2], w_col0[2], len[2];
+  float drop_rate; uint32_t drop_stream; long drop_ld; int drop_off; /* srcB only                  */
+} asr_rnn_back_src;
 typedef struct asr_rnn_step_bwd {
-  int KSt, NT;
-  const float* Wpb;
-  /* d loss / d (state h leaving the cell) = sum_q slabA[q][b][colA + j] + addA[b][j]               */
-  const float* slabA; int QA; long slabA_qstride, slabA_ld; int colA;
-  const float* addA; long addA_ld;
-  /* d loss / d (emitted output y)         = sum_q slabB[q][b][colB + j] + addB[b][j]               */
-  const float* slabB; int QB; long slabB_qstride, slabB_ld; int colB;
-  const float* addB; long addB_ld;
-  float dropB_rate; uint32_t dropB_stream; long dropB_ld; int dropB_off; /* > 0: the slabB sum is the gradient of a dropped-out
-                                               input: multiply by mult(stream, b*dropB_ld + dropB_off + j)                  */
+  int n_units;                              /* H (cell mode) / output width (linear mode)          */
+  asr_rnn_back_src srcA, srcB;
+  const float* addA; long addA_ld;          /* dense addend of the state gradient                  */
+  const float* addB; long addB_ld;          /* dense addend of the output gradient                 */
+  float* direct; long direct_ld;            /* [B,H] carried part of dh (masked rows, GRU z*dh): read then rewritten, or NULL */
+  float* out; long out_ld;                  /* linear mode output                                  */
   float* dc; long dc_ld;                    /* LSTM cell-state gradient, updated in place          */
   float* dy_carry; long dy_carry_ld;        /* pending output gradient across masked steps or NULL */
   const uint8_t* mask; long mask_ld;
@@ -266,17 +272,10 @@ typedef struct asr_rnn_step_bwd {
   const float* h_prev; long h_prev_ld;
   const float* c_prev; long c_prev_ld;
   const float* c_out; long c_out_ld;
-  float* dslots; long dslots_ld;            /* out: gradient wrt the gate sums [B, NS*H] (may alias saved) */
-  float* slab_out; long slab_out_qstride, slab_out_ld; /* out: [Q][Bpad][16 NT] partial input gradients or NULL */
-  int hcol;                                 /* first packed column of the recurrent segment        */
+  float* dslots; long dslots_ld;            /* out: ds [B, NS*H] (may alias saved)                 */
 } asr_rnn_step_bwd;
-int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream);
+int asr_rnn_cell_bwd(int rnn_type, int B, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream);
 
-/* out[b][c] (+)= (sum_q slab[q][b][col0 + c]) * drop (+ add[b][c]);
- * drop = mult(drop_stream, b*drop_ld + drop_off + c) when drop_rate > 0 (gradient of a dropped-out cell input) */
-int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
-                    long add_ld, float* out, long out_ld, int accumulate, const uint32_t* seed, uint32_t drop_stream,
-                    float drop_rate, long drop_ld, int drop_off, void* stream);
 
 /* A whole (Bi)RNN layer over time.  Tensors are batch-major: pre [B,T,G*H] (input projection incl.
  * bias), hseq/cseq [B,T,H] (states after each step, time order), y [B,T,y_ld] with direction d
@@ -286,7 +285,8 @@ typedef struct asr_rnn_seq {
   int rnn_type, B, T, H, ndir;
   int reverse[2];                           /* 1: go_backwards                                      */
   const float* pre[2];
-  const float* Wp[2]; const float* Wpb[2];
+  const float* Wp[2];                       /* packed recurrent kernels (asr_rnn_pack)              */
+  const float* U[2]; long ldu[2];           /* recurrent kernels [H, G*H] in the Keras layout (backward) */
   const float* bias_rec[2];                 /* GRU                                                   */
   const float* h0[2]; long h0_ld[2];        /* initial states (NULL = zeros)                         */
   const float* c0[2]; long c0_ld[2];
@@ -303,7 +303,7 @@ typedef struct asr_rnn_seq_grad {
   const float* dh_last[2]; long dh_last_ld[2]; /* gradient wrt the final h state or NULL            */
   float* dc[2];                             /* [B,H]: in = gradient wrt final c, out = wrt initial c */
   float* dy_carry[2];                       /* [B,H] scratch, zeroed by the caller (masked runs)     */
-  float* slab[2];                           /* scratch: 2 * Q * Bpad * slab_ld floats per direction  */
+  float* direct[2];                         /* scratch [B,H] per direction (zeroed by the call)      */
   float* dh0[2]; long dh0_ld[2];            /* out: gradient wrt initial h or NULL                   */
 } asr_rnn_seq_grad;
 /* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs. */

@@ -32,8 +32,7 @@ class GemmDesc(C.Structure):
 
 
 class RnnGeom(C.Structure):
-    _fields_ = [("Q", C.c_int), ("KSt", C.c_int), ("NT", C.c_int), ("ks0", C.c_int * RNN_MAXSEG),
-                ("wp_floats", c_long), ("wpb_floats", c_long), ("slab_ld", C.c_int)]
+    _fields_ = [("Q", C.c_int), ("KSt", C.c_int), ("ks0", C.c_int * RNN_MAXSEG), ("wp_floats", c_long)]
 
 
 class RnnStepFwd(C.Structure):
@@ -49,23 +48,25 @@ class RnnStepFwd(C.Structure):
                 ("y_out", c_f32p), ("y_out_ld", c_long), ("saved", c_f32p), ("saved_ld", c_long)]
 
 
+class RnnBackSrc(C.Structure):
+    _fields_ = [("D", c_f32p), ("ldd", c_long), ("W", c_f32p), ("ldw", c_long), ("nseg", C.c_int), ("d_col0", C.c_int * 2),
+                ("w_col0", C.c_int * 2), ("len", C.c_int * 2), ("drop_rate", C.c_float), ("drop_stream", C.c_uint32),
+                ("drop_ld", c_long), ("drop_off", C.c_int)]
+
+
 class RnnStepBwd(C.Structure):
-    _fields_ = [("KSt", C.c_int), ("NT", C.c_int), ("Wpb", c_f32p),
-                ("slabA", c_f32p), ("QA", C.c_int), ("slabA_qstride", c_long), ("slabA_ld", c_long), ("colA", C.c_int),
-                ("addA", c_f32p), ("addA_ld", c_long),
-                ("slabB", c_f32p), ("QB", C.c_int), ("slabB_qstride", c_long), ("slabB_ld", c_long), ("colB", C.c_int),
-                ("addB", c_f32p), ("addB_ld", c_long),
-                ("dropB_rate", C.c_float), ("dropB_stream", C.c_uint32), ("dropB_ld", c_long), ("dropB_off", C.c_int),
+    _fields_ = [("n_units", C.c_int), ("srcA", RnnBackSrc), ("srcB", RnnBackSrc),
+                ("addA", c_f32p), ("addA_ld", c_long), ("addB", c_f32p), ("addB_ld", c_long),
+                ("direct", c_f32p), ("direct_ld", c_long), ("out", c_f32p), ("out_ld", c_long),
                 ("dc", c_f32p), ("dc_ld", c_long), ("dy_carry", c_f32p), ("dy_carry_ld", c_long),
                 ("mask", c_f32p), ("mask_ld", c_long), ("saved", c_f32p), ("saved_ld", c_long),
                 ("h_prev", c_f32p), ("h_prev_ld", c_long), ("c_prev", c_f32p), ("c_prev_ld", c_long),
-                ("c_out", c_f32p), ("c_out_ld", c_long), ("dslots", c_f32p), ("dslots_ld", c_long),
-                ("slab_out", c_f32p), ("slab_out_qstride", c_long), ("slab_out_ld", c_long), ("hcol", C.c_int)]
+                ("c_out", c_f32p), ("c_out_ld", c_long), ("dslots", c_f32p), ("dslots_ld", c_long)]
 
 
 class RnnSeq(C.Structure):
     _fields_ = [("rnn_type", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("ndir", C.c_int),
-                ("reverse", C.c_int * 2), ("pre", c_f32p * 2), ("Wp", c_f32p * 2), ("Wpb", c_f32p * 2),
+                ("reverse", C.c_int * 2), ("pre", c_f32p * 2), ("Wp", c_f32p * 2), ("U", c_f32p * 2), ("ldu", c_long * 2),
                 ("bias_rec", c_f32p * 2), ("h0", c_f32p * 2), ("h0_ld", c_long * 2), ("c0", c_f32p * 2),
                 ("c0_ld", c_long * 2), ("rec_mult", c_f32p * 2), ("mask", c_f32p),
                 ("hseq", c_f32p * 2), ("cseq", c_f32p * 2), ("y", c_f32p), ("y_ld", c_long), ("y_col", C.c_int * 2),
@@ -74,7 +75,7 @@ class RnnSeq(C.Structure):
 
 class RnnSeqGrad(C.Structure):
     _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
-                ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("slab", c_f32p * 2), ("dh0", c_f32p * 2),
+                ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("direct", c_f32p * 2), ("dh0", c_f32p * 2),
                 ("dh0_ld", c_long * 2)]
 
 
@@ -94,7 +95,7 @@ class LrSchedule(C.Structure):
 
 
 STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom,
-           "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
+           "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_back_src": RnnBackSrc, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
            "asr_rnn_seq_grad": RnnSeqGrad, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
            "asr_lr_schedule": LrSchedule}
 
@@ -110,11 +111,9 @@ SIGNATURES = {
     "asr_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
-                               C.POINTER(C.c_int), _P, _P, _P]),
+                               C.POINTER(C.c_int), _P, _P]),
     "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
-    "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
-    "asr_slab_reduce": (C.c_int, [_P, C.c_int, c_long, c_long, C.c_int, C.c_int, C.c_int, _P, c_long, _P, c_long,
-                                  C.c_int, _P, C.c_uint32, C.c_float, c_long, C.c_int, _P]),
+    "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),

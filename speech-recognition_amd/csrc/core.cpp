@@ -24,6 +24,7 @@ extern "C" long asr_struct_size(const char* name) {
   SZ(asr_gemm_desc);
   SZ(asr_rnn_geom);
   SZ(asr_rnn_step_fwd);
+  SZ(asr_rnn_back_src);
   SZ(asr_rnn_step_bwd);
   SZ(asr_rnn_seq);
   SZ(asr_rnn_seq_grad);

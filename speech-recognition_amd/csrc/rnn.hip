@@ -34,7 +34,6 @@ static __host__ __device__ inline int cell_nsaved(int cell) { return cell == CEL
 //   W[k = 16*blk + 4*lq + e][slot] - so one float4 per lane feeds 4 consecutive MFMA 16x16x4 steps and
 //   matches a float4 of the activation row loaded by the same lane (the k labelling inside a block is
 //   free as long as A and B agree).
-// Backward image Wpb[Q][KB][64 lanes][4]: lane (lq, li), element s4 holds W[k = 16*blk + li][slot = 4*s4 + lq].
 struct PackArgs {
   const float* W[ASR_RNN_MAXSEG];
   long ldw[ASR_RNN_MAXSEG];
@@ -43,7 +42,6 @@ struct PackArgs {
   int is_rec[ASR_RNN_MAXSEG];
   int nseg, KSt, NT, H, Q, cell;
   float* Wp;
-  float* Wpb;
 };
 
 __device__ __forceinline__ float pack_value(const PackArgs& a, int q, int kcol, int slot) {
@@ -69,13 +67,11 @@ __device__ __forceinline__ float pack_value(const PackArgs& a, int q, int kcol, 
 
 __global__ void rnn_pack_kernel(PackArgs a) {
   const long nf = (long)a.Q * a.KSt * 256;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * nf; i += (long)gridDim.x * blockDim.x) {
-    const long i2 = i < nf ? i : i - nf;
-    const int e = (int)(i2 & 3), lane = (int)((i2 >> 2) & 63);
-    const long r = i2 >> 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long r = i >> 8;
     const int blk = (int)(r % a.KSt), q = (int)(r / a.KSt);
-    if (i < nf) a.Wp[i2] = pack_value(a, q, 16 * blk + 4 * (lane >> 4) + e, lane & 15);
-    else a.Wpb[i2] = pack_value(a, q, 16 * blk + (lane & 15), 4 * e + (lane >> 4));
+    a.Wp[i] = pack_value(a, q, 16 * blk + 4 * (lane >> 4) + e, lane & 15);
   }
 }
 
@@ -227,210 +223,6 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   if (d.y_out) d.y_out[(long)b * d.y_out_ld + j] = m ? hn : yp;
 }
 
-// ------------------------------------------------------------------------------------------ backward step
-struct BwdDir {
-  int KSt, NT;             // packed 16-wide K blocks (NT == KSt: one slab column tile per block)
-  const float* Wpb;
-  // gradient wrt the state h leaving this cell:  sum_q slabA[q][b][colA + j]  +  addA[b][j]
-  const float* slabA; int QA; long slabA_qstride; long slabA_ld; int colA;
-  const float* addA; long addA_ld;
-  // gradient wrt the emitted output y:           sum_q slabB[q][b][colB + j]  +  addB[b][j]
-  const float* slabB; int QB; long slabB_qstride; long slabB_ld; int colB;
-  const float* addB; long addB_ld;
-  float dropB_rate; uint32_t dropB_stream; long dropB_ld; int dropB_off;
-  float* dc; long dc_ld;               // cell-state gradient, updated in place (LSTM)
-  float* dy_carry; long dy_carry_ld;   // pending output gradient of masked steps (sequence use), may be null
-  const uint8_t* mask; long mask_ld;
-  const float* saved; long saved_ld;   // activations saved by the forward step
-  const float* h_prev; long h_prev_ld; // GRU
-  const float* c_prev; long c_prev_ld; // LSTM
-  const float* c_out; long c_out_ld;   // LSTM: c after this step
-  float* dslots; long dslots_ld;       // [B][NS*H] gradient wrt the gate pre-activation sums (may alias saved)
-  float* slab_out; long slab_out_qstride; long slab_out_ld;  // [Q][Bpad][16*KSt]
-  int hcol;                // first packed column of the recurrent segment
-};
-struct BwdArgs { BwdDir d[2]; int B, H; const uint32_t* seed; };
-
-// sum over q' = wave, wave+4, ... of slab[q'][b][col]: independent loads issued 8 at a time
-__device__ __forceinline__ float slab_partial(const float* slab, int Q, long qstride, long off, int wave) {
-  float s = 0.f;
-  for (int q0 = wave; q0 < Q; q0 += 32) {
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const int qq = q0 + 4 * i; v[i] = qq < Q ? slab[(long)qq * qstride + off] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-  }
-  return s;
-}
-
-template <int CELL>
-__global__ __launch_bounds__(256) void rnn_step_bwd_kernel(BwdArgs a) {
-  __shared__ float red[4][64];
-  __shared__ float red2[4][64];
-  __shared__ float dp[16 * 17];
-  __shared__ float direct[16 * 4];
-  const BwdDir& d = a.d[blockIdx.z];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lq = lane >> 4;
-  const int q = blockIdx.x, b0 = blockIdx.y * 16;
-  const int H = a.H, B = a.B;
-  const int bi = lane >> 2, u = lane & 3;
-  const int b = b0 + bi, j = 4 * q + u;
-  const bool live = b < B && j < H;
-
-  // backward-image fragments of this workgroup's K blocks: issue the loads before anything else
-  const float4* wb = reinterpret_cast<const float4*>(d.Wpb) + (long)q * d.KSt * 64 + lane;
-  float4 bw0[RNN_CH];
-#pragma unroll
-  for (int i = 0; i < RNN_CH; ++i) {
-    const int nt = wave + 4 * i;
-    bw0[i] = (d.slab_out != nullptr && nt < d.KSt) ? wb[(long)nt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // operands of the gate-gradient math (wave 0): issue their loads before the slab sums so the two
-  // memory round trips overlap
-  constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
-  bool m = true;
-  float carry = 0.f, svv[NSV], cpv = 0.f, cov = 0.f, dcv = 0.f, hpv = 0.f, addAv = 0.f, addBv = 0.f;
-#pragma unroll
-  for (int g = 0; g < NSV; ++g) svv[g] = 0.f;
-  if (wave == 0 && live) {
-    m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
-    carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
-    const float* sv = d.saved + (long)b * d.saved_ld + j;
-#pragma unroll
-    for (int g = 0; g < NSV; ++g) svv[g] = sv[(long)g * H];
-    if (d.addA) addAv = d.addA[(long)b * d.addA_ld + j];
-    if (d.addB) addBv = d.addB[(long)b * d.addB_ld + j];
-    if (CELL == CELL_LSTM) {
-      cpv = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
-      cov = d.c_out[(long)b * d.c_out_ld + j];
-      dcv = d.dc[(long)b * d.dc_ld + j];
-    }
-    if (CELL == CELL_GRU) hpv = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
-  }
-
-  // 1. slab reduction, spread over the 4 waves
-  float sa = 0.f, sb = 0.f;
-  if (live) {
-    if (d.slabA) sa = slab_partial(d.slabA, d.QA, d.slabA_qstride, (long)b * d.slabA_ld + d.colA + j, wave);
-    if (d.slabB) sb = slab_partial(d.slabB, d.QB, d.slabB_qstride, (long)b * d.slabB_ld + d.colB + j, wave);
-  }
-  red[wave][lane] = sa;
-  red2[wave][lane] = sb;
-  __syncthreads();
-
-  // 2. gate gradients (wave 0)
-  if (wave == 0) {
-    float dh_state = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    float dy = red2[0][lane] + red2[1][lane] + red2[2][lane] + red2[3][lane];
-    if (d.dropB_rate > 0.f && live) {
-      const AsrRngKey key = asr_rng_key(a.seed[0], d.dropB_stream);
-      dy *= asr_drop_mult(key, (uint32_t)((long)b * d.dropB_ld + d.dropB_off + j), asr_drop_threshold(d.dropB_rate), 1.f / (1.f - d.dropB_rate));
-    }
-    float ds[4] = {0.f, 0.f, 0.f, 0.f};
-    float dir = 0.f;
-    if (live) {
-      dh_state += addAv;
-      dy += addBv;
-      if (!m) {
-        dir = dh_state;                       // state carried unchanged
-        if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = carry + dy;
-        // dc stays as it is
-      } else {
-        const float dh = dh_state + dy + carry;
-        if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = 0.f;
-        if (CELL == CELL_LSTM) {
-          const float ig = svv[0], fg = svv[NSV > 1 ? 1 : 0], gg = svv[NSV > 2 ? 2 : 0], og = svv[NSV > 3 ? 3 : 0];
-          const float tc = tanhf_(cov);
-          const float dct = dcv + dh * og * (1.f - tc * tc);
-          ds[0] = dct * gg * ig * (1.f - ig);
-          ds[1] = dct * cpv * fg * (1.f - fg);
-          ds[2] = dct * ig * (1.f - gg * gg);
-          ds[3] = dh * tc * og * (1.f - og);
-          d.dc[(long)b * d.dc_ld + j] = dct * fg;
-        } else if (CELL == CELL_GRU) {
-          const float z = svv[0], r = svv[NSV > 1 ? 1 : 0], hh = svv[NSV > 2 ? 2 : 0], arh = svv[NSV > 3 ? 3 : 0];
-          const float dahh = dh * (1.f - z) * (1.f - hh * hh);
-          ds[0] = dh * (hpv - hh) * z * (1.f - z);
-          ds[1] = dahh * arh * r * (1.f - r);
-          ds[2] = dahh;
-          ds[3] = dahh * r;
-          dir = dh * z;
-        } else {
-          const float hn = svv[0];
-          ds[0] = dh * (1.f - hn * hn);
-        }
-      }
-      float* o = d.dslots + (long)b * d.dslots_ld + j;
-#pragma unroll
-      for (int g = 0; g < NSV; ++g) o[(long)g * H] = ds[g];
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) dp[bi * 17 + g * 4 + u] = ds[g];
-    direct[bi * 4 + u] = dir;
-  }
-  __syncthreads();
-
-  // 3. partial product dA[16 x Ktot] = dslots[16 x 16] x Wslice^T  -> slab (plus the direct term)
-  if (d.slab_out == nullptr) return;
-  float av[4];
-#pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) av[s4] = dp[li * 17 + 4 * s4 + lq];
-  for (int n0 = wave; n0 < d.KSt; n0 += 4 * RNN_CH) {
-    float4 bw[RNN_CH];
-#pragma unroll
-    for (int i = 0; i < RNN_CH; ++i) {
-      const int nt = n0 + 4 * i;
-      bw[i] = n0 == wave ? bw0[i] : (nt < d.KSt ? wb[(long)nt * 64] : make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-#pragma unroll
-    for (int i = 0; i < RNN_CH; ++i) {
-      const int nt = n0 + 4 * i;
-      if (nt >= d.KSt) continue;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bw[i].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bw[i].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bw[i].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bw[i].w, acc, 0, 0, 0);
-      const int col = nt * 16 + li;
-      const int own = col - d.hcol - 4 * q;  // 0..3 when this column is one of the owned units' h columns
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lq * 4 + r;
-        float v = acc[r];
-        if (own >= 0 && own < 4) v += direct[row * 4 + own];
-        d.slab_out[(long)q * d.slab_out_qstride + (long)(b0 + row) * d.slab_out_ld + col] = v;
-      }
-    }
-  }
-}
-
-// sum of slabs: out[b][c] (+)= (sum_q slab[q][b][col0 + c]) * drop (+ add[b][c]).
-// Block = 64 outputs x 4 q-lanes; each thread keeps 8 independent loads in flight.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B,
-                                                          const float* add, long add_ld, float* out, long out_ld, int accumulate,
-                                                          const uint32_t* seed, uint32_t drop_stream, float drop_rate, long drop_ld,
-                                                          int drop_off) {
-  __shared__ float red[4][64];
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + l;
-  const bool live = i < (long)B * ncols;
-  const int b = live ? (int)(i / ncols) : 0, c = live ? (int)(i % ncols) : 0;
-  red[w][l] = live ? slab_partial(slab, Q, qstride, (long)b * ld + col0 + c, w) : 0.f;
-  __syncthreads();
-  if (w != 0 || !live) return;
-  float s = red[0][l] + red[1][l] + red[2][l] + red[3][l];
-  if (drop_rate > 0.f) {
-    const AsrRngKey key = asr_rng_key(seed[0], drop_stream);
-    s *= asr_drop_mult(key, (uint32_t)((long)b * drop_ld + drop_off + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
-  }
-  if (add) s += add[(long)b * add_ld + c];
-  float* o = out + (long)b * out_ld + c;
-  *o = accumulate ? *o + s : s;
-}
-
 // ------------------------------------------------------------------------------------------ host side
 static int cell_from_name(int rnn_type) { return rnn_type; }
 
@@ -443,23 +235,20 @@ extern "C" int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr
   for (int i = 0; i < ASR_RNN_MAXSEG; ++i) g->ks0[i] = 0;
   for (int i = 0; i < nseg; ++i) { g->ks0[i] = ks; ks += asr_cdiv(K[i], 16); }
   g->KSt = ks;
-  g->NT = ks;
   g->wp_floats = (long)g->Q * g->KSt * 256;
-  g->wpb_floats = (long)g->Q * g->KSt * 256;
-  g->slab_ld = g->KSt * 16;
   return ASR_OK;
 }
 
 extern "C" int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const long* ldw, const int* K,
-                            const int* is_rec, float* Wp, float* Wpb, void* stream) {
-  ASR_CHECK(W && ldw && K && is_rec && Wp && Wpb, ASR_ERR_ARG, "asr_rnn_pack: null argument");
+                            const int* is_rec, float* Wp, void* stream) {
+  ASR_CHECK(W && ldw && K && is_rec && Wp, ASR_ERR_ARG, "asr_rnn_pack: null argument");
   asr_rnn_geom g;
   int rc = asr_rnn_geometry(rnn_type, H, nseg, K, &g);
   if (rc) return rc;
   PackArgs a{};
   for (int i = 0; i < nseg; ++i) { a.W[i] = W[i]; a.ldw[i] = ldw[i]; a.K[i] = K[i]; a.ks0[i] = g.ks0[i]; a.is_rec[i] = is_rec[i]; }
-  a.nseg = nseg; a.KSt = g.KSt; a.NT = g.NT; a.H = H; a.Q = g.Q; a.cell = cell_from_name(rnn_type); a.Wp = Wp; a.Wpb = Wpb;
-  const long n = g.wp_floats + g.wpb_floats;
+  a.nseg = nseg; a.KSt = g.KSt; a.NT = g.KSt; a.H = H; a.Q = g.Q; a.cell = cell_from_name(rnn_type); a.Wp = Wp;
+  const long n = g.wp_floats;
   hipLaunchKernelGGL(rnn_pack_kernel, dim3((unsigned)min((long)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -558,126 +347,3 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
   return ASR_OK;
 }
 
-static void fill_bwd_dir(BwdDir* d, const asr_rnn_step_bwd* s) {
-  *d = BwdDir{};
-  d->KSt = s->KSt; d->NT = s->NT; d->Wpb = s->Wpb;
-  d->slabA = s->slabA; d->QA = s->QA; d->slabA_qstride = s->slabA_qstride; d->slabA_ld = s->slabA_ld; d->colA = s->colA;
-  d->addA = s->addA; d->addA_ld = s->addA_ld;
-  d->slabB = s->slabB; d->QB = s->QB; d->slabB_qstride = s->slabB_qstride; d->slabB_ld = s->slabB_ld; d->colB = s->colB;
-  d->addB = s->addB; d->addB_ld = s->addB_ld;
-  d->dropB_rate = s->dropB_rate; d->dropB_stream = s->dropB_stream; d->dropB_ld = s->dropB_ld; d->dropB_off = s->dropB_off;
-  d->dc = s->dc; d->dc_ld = s->dc_ld; d->dy_carry = s->dy_carry; d->dy_carry_ld = s->dy_carry_ld;
-  d->mask = s->mask; d->mask_ld = s->mask_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
-  d->h_prev = s->h_prev; d->h_prev_ld = s->h_prev_ld; d->c_prev = s->c_prev; d->c_prev_ld = s->c_prev_ld;
-  d->c_out = s->c_out; d->c_out_ld = s->c_out_ld; d->dslots = s->dslots; d->dslots_ld = s->dslots_ld;
-  d->slab_out = s->slab_out; d->slab_out_qstride = s->slab_out_qstride; d->slab_out_ld = s->slab_out_ld; d->hcol = s->hcol;
-}
-
-static int launch_bwd(int rnn_type, const BwdArgs& a, int ndir, hipStream_t st) {
-  dim3 grid((unsigned)asr_cdiv(a.H, 4), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_RNN>, grid, dim3(256), 0, st, a);
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
-}
-
-extern "C" int asr_rnn_cell_bwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream) {
-  ASR_CHECK(steps, ASR_ERR_ARG, "asr_rnn_cell_bwd: null argument");
-  ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
-  ASR_CHECK(B > 0 && H > 0 && (ndir == 1 || ndir == 2), ASR_ERR_SHAPE, "asr_rnn_cell_bwd: B %d H %d ndir %d", B, H, ndir);
-  BwdArgs a{};
-  a.B = B; a.H = H; a.seed = seed;
-  for (int i = 0; i < ndir; ++i) {
-    ASR_CHECK(steps[i].saved && steps[i].dslots, ASR_ERR_ARG, "asr_rnn_cell_bwd: saved/dslots missing");
-    ASR_CHECK(!(steps[i].dropB_rate > 0.f && !seed), ASR_ERR_ARG, "asr_rnn_cell_bwd: dropout needs a device seed");
-    ASR_CHECK(rnn_type != CELL_LSTM || (steps[i].dc && steps[i].c_out), ASR_ERR_ARG, "asr_rnn_cell_bwd: LSTM needs dc and c_out");
-    ASR_CHECK(!steps[i].slab_out || steps[i].Wpb, ASR_ERR_ARG, "asr_rnn_cell_bwd: slab_out needs Wpb");
-    fill_bwd_dir(&a.d[i], &steps[i]);
-  }
-  return launch_bwd(rnn_type, a, ndir, (hipStream_t)stream);
-}
-
-// Whole BiRNN layer backward-through-time.  On return:
-//   saved[d] holds dslots (gradient wrt the gate sums) for the batched dW / dU / dX GEMMs,
-//   dh0[d] / dc0[d] hold the gradient wrt the initial states (if non-null).
-extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs, void* stream) {
-  ASR_CHECK(s && gs, ASR_ERR_ARG, "asr_rnn_seq_bwd: null argument");
-  ASR_CHECK(s->rnn_type >= 0 && s->rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", s->rnn_type);
-  const int B = s->B, T = s->T, H = s->H;
-  const int NS = cell_nsaved(s->rnn_type);
-  const bool lstm = s->rnn_type == CELL_LSTM;
-  asr_rnn_geom g;
-  int K1[1] = {H};
-  asr_rnn_geometry(s->rnn_type, H, 1, K1, &g);
-  const int Bpad = asr_cdiv(B, 16) * 16;
-  const long qstride = (long)Bpad * g.slab_ld;
-  const long slab_floats = (long)g.Q * qstride;
-  for (int d = 0; d < s->ndir; ++d) {
-    ASR_CHECK(s->saved[d] && s->Wpb[d] && gs->slab[d] && gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd: null buffer (dir %d)", d);
-    ASR_CHECK(!lstm || gs->dc[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: LSTM needs a dc buffer (dir %d)", d);
-    ASR_CHECK(!s->mask || gs->dy_carry[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: masked sequences need dy_carry (dir %d)", d);
-  }
-  hipStream_t st = (hipStream_t)stream;
-  for (int step = T - 1; step >= 0; --step) {
-    BwdArgs a{};
-    a.B = B; a.H = H; a.seed = nullptr;
-    for (int d = 0; d < s->ndir; ++d) {
-      const bool rev = s->reverse[d] != 0;
-      const int t = rev ? T - 1 - step : step;
-      const int tp = rev ? t + 1 : t - 1;
-      BwdDir& bd = a.d[d];
-      bd = BwdDir{};
-      bd.KSt = g.KSt; bd.NT = g.NT; bd.Wpb = s->Wpb[d];
-      float* slab_cur = gs->slab[d] + (long)(step & 1) * slab_floats;        // written by this step
-      const float* slab_nxt = gs->slab[d] + (long)((step + 1) & 1) * slab_floats;  // written by step+1
-      if (step == T - 1) {
-        bd.slabA = nullptr; bd.addA = gs->dh_last[d]; bd.addA_ld = gs->dh_last_ld[d];
-      } else {
-        bd.slabA = slab_nxt; bd.QA = g.Q; bd.slabA_qstride = qstride; bd.slabA_ld = g.slab_ld; bd.colA = 0;
-      }
-      bd.slabB = nullptr;
-      bd.addB = gs->dy + (long)t * gs->dy_ld + s->y_col[d]; bd.addB_ld = (long)T * gs->dy_ld;
-      bd.dc = lstm ? gs->dc[d] : nullptr; bd.dc_ld = H;
-      bd.dy_carry = s->mask ? gs->dy_carry[d] : nullptr; bd.dy_carry_ld = H;
-      bd.mask = s->mask ? s->mask + t : nullptr; bd.mask_ld = T;
-      bd.saved = s->saved[d] + (long)t * NS * H; bd.saved_ld = (long)T * NS * H;
-      if (step == 0) {
-        bd.h_prev = s->h0[d]; bd.h_prev_ld = s->h0_ld[d];
-        bd.c_prev = lstm ? s->c0[d] : nullptr; bd.c_prev_ld = s->c0_ld[d];
-      } else {
-        bd.h_prev = s->hseq[d] + (long)tp * H; bd.h_prev_ld = (long)T * H;
-        bd.c_prev = lstm ? s->cseq[d] + (long)tp * H : nullptr; bd.c_prev_ld = (long)T * H;
-      }
-      bd.c_out = lstm ? s->cseq[d] + (long)t * H : nullptr; bd.c_out_ld = (long)T * H;
-      bd.dslots = s->saved[d] + (long)t * NS * H; bd.dslots_ld = (long)T * NS * H;
-      bd.slab_out = slab_cur; bd.slab_out_qstride = qstride; bd.slab_out_ld = g.slab_ld; bd.hcol = 0;
-    }
-    int rc = launch_bwd(s->rnn_type, a, s->ndir, st);
-    if (rc) return rc;
-  }
-  // gradient wrt the initial state = sum of the slabs written by step 0
-  for (int d = 0; d < s->ndir; ++d) {
-    if (gs->dh0[d]) {
-      const float* slab0 = gs->slab[d];  // step 0 -> parity 0
-      const long n = (long)B * H;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab0, g.Q,
-                         qstride, (long)g.slab_ld, 0, H, B, (const float*)nullptr, 0L, gs->dh0[d], gs->dh0_ld[d], 0,
-                         (const uint32_t*)nullptr, 0u, 0.f, 0L, 0);
-    }
-  }
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
-}
-
-extern "C" int asr_slab_reduce(const float* slab, int Q, long qstride, long ld, int col0, int ncols, int B, const float* add,
-                               long add_ld, float* out, long out_ld, int accumulate, const uint32_t* seed, uint32_t drop_stream,
-                               float drop_rate, long drop_ld, int drop_off, void* stream) {
-  ASR_CHECK(slab && out && Q > 0 && B > 0 && ncols > 0, ASR_ERR_ARG, "asr_slab_reduce: bad argument");
-  ASR_CHECK(!(drop_rate > 0.f && !seed), ASR_ERR_ARG, "asr_slab_reduce: dropout needs a device seed");
-  const long n = (long)B * ncols;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, slab,
-                     Q, qstride, ld, col0, ncols, B, add, add_ld, out, out_ld, accumulate, seed, drop_stream, drop_rate, drop_ld, drop_off);
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
-}

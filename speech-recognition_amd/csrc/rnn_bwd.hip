@@ -1,0 +1,331 @@
+// Backward step of the recurrent cells (gradient of rnn.hip's forward step) for gfx950.
+//
+// The quantity handed from one backward step to the next is ds, the gradient with respect to the
+// gate pre-activation sums ("slots", [B, NS*H], written in place over the saved activations) - the
+// mirror image of the forward pass handing h around.  A step's workgroup owns 16 hidden units x 16
+// batch rows and computes, for those units only,
+//     dh[b, j] = sum_c ds_consumer[b, c] * W_consumer[j, c]          (consumer = the cell(s) that read h_j)
+// straight from the Keras-layout weights (row j of the recurrent / input kernel is contiguous), with
+// the c axis split over the workgroup's 16 waves (v_mfma_f32_16x16x4_f32, both operands loaded as one
+// float4 per lane per 16 columns), reduced through LDS, followed by the gate-gradient math of the
+// owned units.  Compared with a K-split over workgroups (partial-sum slabs) this writes 16x less
+// data per launch - and a dependent launch on MI355X is priced mostly by the dirty lines it leaves.
+// A second "linear" mode of the same kernel only forms the sums (gradients of cell inputs that are
+// not states: the attention context, the initial states).
+#include "common.h"
+
+#define CELL_LSTM 0
+#define CELL_GRU 1
+#define CELL_RNN 2
+#define BW_NW 16      // waves per workgroup
+#define BW_CH 4       // 16-column blocks a wave keeps in flight
+
+struct BackSrc {
+  const float* D; long ldd;
+  const float* W; long ldw;
+  int nseg; int d_col0[2], w_col0[2], len[2];
+  int vec;
+  float drop_rate; uint32_t drop_stream; long drop_ld; int drop_off;
+};
+struct Bwd2Dir {
+  int n_units;
+  BackSrc src[2];                      // [0] -> gradient wrt the state h, [1] -> gradient wrt the emitted output y
+  const float* addA; long addA_ld;
+  const float* addB; long addB_ld;
+  float* direct; long direct_ld;       // carried part of dh (masked rows / GRU z * dh): read, then overwritten
+  float* out; long out_ld;             // linear mode when non-null
+  float* dc; long dc_ld;
+  float* dy_carry; long dy_carry_ld;
+  const uint8_t* mask; long mask_ld;
+  const float* saved; long saved_ld;
+  const float* h_prev; long h_prev_ld;
+  const float* c_prev; long c_prev_ld;
+  const float* c_out; long c_out_ld;
+  float* dslots; long dslots_ld;
+};
+struct Bwd2Args { Bwd2Dir d[2]; int B; const uint32_t* seed; };
+
+// partial[16 rows x 16 units] (this wave's share of the column blocks) of  D[rows, cols] x W[units, cols]^T
+__device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit0, int B, int n_units, int wave, int li, int lq) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (s.D == nullptr) return acc;
+  const int brow = b0 + li, urow = unit0 + li;
+  const bool aok = brow < B, bok = urow < n_units;
+  for (int g = 0; g < s.nseg; ++g) {
+    const int len = s.len[g], nb = (len + 15) >> 4;
+    const float* dr = s.D + (long)brow * s.ldd + s.d_col0[g];
+    const float* wr = s.W + (long)urow * s.ldw + s.w_col0[g];
+    for (int j0 = wave; j0 < nb; j0 += BW_NW * BW_CH) {
+      float4 av[BW_CH], bv[BW_CH];
+#pragma unroll
+      for (int i = 0; i < BW_CH; ++i) {
+        const int jb = j0 + BW_NW * i, k = 16 * jb + 4 * lq;
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jb < nb) {
+          if (s.vec && k + 3 < len) {
+            if (aok) av[i] = *reinterpret_cast<const float4*>(dr + k);
+            if (bok) bv[i] = *reinterpret_cast<const float4*>(wr + k);
+          } else {
+            if (aok) { av[i].x = k < len ? dr[k] : 0.f; av[i].y = k + 1 < len ? dr[k + 1] : 0.f; av[i].z = k + 2 < len ? dr[k + 2] : 0.f; av[i].w = k + 3 < len ? dr[k + 3] : 0.f; }
+            if (bok) { bv[i].x = k < len ? wr[k] : 0.f; bv[i].y = k + 1 < len ? wr[k + 1] : 0.f; bv[i].z = k + 2 < len ? wr[k + 2] : 0.f; bv[i].w = k + 3 < len ? wr[k + 3] : 0.f; }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BW_CH; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  return acc;
+}
+
+template <int CELL>
+__global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_kernel(Bwd2Args a) {
+  __shared__ float part[2][BW_NW][256];
+  const Bwd2Dir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int unit0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int B = a.B, H = d.n_units;
+  // thread (row, un) of the first 256 threads owns one (batch row, unit) pair for the gate math
+  const int row = tid >> 4, un = tid & 15;
+  const int b = b0 + row, j = unit0 + un;
+  const bool owner = tid < 256 && b < B && j < H;
+  const bool linear = d.out != nullptr;
+
+  // operands of the element-wise part: loads issued before the matrix products
+  constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
+  bool m = true;
+  float carry = 0.f, svv[NSV], cpv = 0.f, cov = 0.f, dcv = 0.f, hpv = 0.f, addAv = 0.f, addBv = 0.f, dirv = 0.f;
+#pragma unroll
+  for (int g = 0; g < NSV; ++g) svv[g] = 0.f;
+  if (owner) {
+    if (d.addA) addAv = d.addA[(long)b * d.addA_ld + j];
+    if (d.addB) addBv = d.addB[(long)b * d.addB_ld + j];
+    if (d.direct) dirv = d.direct[(long)b * d.direct_ld + j];
+    if (!linear) {
+      m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+      carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
+      const float* sv = d.saved + (long)b * d.saved_ld + j;
+#pragma unroll
+      for (int g = 0; g < NSV; ++g) svv[g] = sv[(long)g * H];
+      if (CELL == CELL_LSTM) {
+        cpv = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+        cov = d.c_out[(long)b * d.c_out_ld + j];
+        dcv = d.dc[(long)b * d.dc_ld + j];
+      }
+      if (CELL == CELL_GRU) hpv = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+    }
+  }
+
+  const f32x4 pa = back_partial(d.src[0], b0, unit0, B, H, wave, li, lq);
+  const f32x4 pb = back_partial(d.src[1], b0, unit0, B, H, wave, li, lq);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {        // C/D map: col = lane&15 (unit), row = 4*(lane>>4) + r (batch row)
+    part[0][wave][(lq * 4 + r) * 16 + li] = pa[r];
+    part[1][wave][(lq * 4 + r) * 16 + li] = pb[r];
+  }
+  __syncthreads();
+  if (!owner) return;
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < BW_NW; ++w) { sa += part[0][w][tid]; sb += part[1][w][tid]; }
+  if (d.src[1].D != nullptr && d.src[1].drop_rate > 0.f) {
+    const BackSrc& s = d.src[1];
+    const AsrRngKey key = asr_rng_key(a.seed[0], s.drop_stream);
+    sb *= asr_drop_mult(key, (uint32_t)((long)b * s.drop_ld + s.drop_off + j), asr_drop_threshold(s.drop_rate), 1.f / (1.f - s.drop_rate));
+  }
+  const float dh_state = sa + addAv + dirv;
+  const float dy = sb + addBv;
+  if (linear) {
+    d.out[(long)b * d.out_ld + j] = dh_state + dy;
+    return;
+  }
+  float ds[4] = {0.f, 0.f, 0.f, 0.f};
+  float dir = 0.f;
+  if (!m) {
+    dir = dh_state;                       // state carried unchanged through a masked step
+    if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = carry + dy;
+  } else {
+    const float dh = dh_state + dy + carry;
+    if (d.dy_carry) d.dy_carry[(long)b * d.dy_carry_ld + j] = 0.f;
+    if (CELL == CELL_LSTM) {
+      const float ig = svv[0], fg = svv[NSV > 1 ? 1 : 0], gg = svv[NSV > 2 ? 2 : 0], og = svv[NSV > 3 ? 3 : 0];
+      const float tc = tanhf_(cov);
+      const float dct = dcv + dh * og * (1.f - tc * tc);
+      ds[0] = dct * gg * ig * (1.f - ig);
+      ds[1] = dct * cpv * fg * (1.f - fg);
+      ds[2] = dct * ig * (1.f - gg * gg);
+      ds[3] = dh * tc * og * (1.f - og);
+      d.dc[(long)b * d.dc_ld + j] = dct * fg;
+    } else if (CELL == CELL_GRU) {
+      const float z = svv[0], r = svv[NSV > 1 ? 1 : 0], hh = svv[NSV > 2 ? 2 : 0], arh = svv[NSV > 3 ? 3 : 0];
+      const float dahh = dh * (1.f - z) * (1.f - hh * hh);
+      ds[0] = dh * (hpv - hh) * z * (1.f - z);
+      ds[1] = dahh * arh * r * (1.f - r);
+      ds[2] = dahh;
+      ds[3] = dahh * r;
+      dir = dh * z;
+    } else {
+      const float hn = svv[0];
+      ds[0] = dh * (1.f - hn * hn);
+    }
+  }
+  float* o = d.dslots + (long)b * d.dslots_ld + j;
+#pragma unroll
+  for (int g = 0; g < NSV; ++g) o[(long)g * H] = ds[g];
+  if (d.direct) d.direct[(long)b * d.direct_ld + j] = dir;
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static inline int cell_nsaved(int cell) { return cell == CELL_RNN ? 1 : 4; }
+
+static int fill_src(BackSrc* o, const asr_rnn_back_src* s) {
+  *o = BackSrc{};
+  if (!s->D) return ASR_OK;
+  ASR_CHECK(s->W && s->nseg >= 1 && s->nseg <= 2, ASR_ERR_ARG, "rnn backward source: weights / segments missing");
+  o->D = s->D; o->ldd = s->ldd; o->W = s->W; o->ldw = s->ldw; o->nseg = s->nseg;
+  bool vec = (((uintptr_t)s->D | (uintptr_t)s->W) & 15) == 0 && s->ldd % 4 == 0 && s->ldw % 4 == 0;
+  for (int g = 0; g < s->nseg; ++g) {
+    o->d_col0[g] = s->d_col0[g]; o->w_col0[g] = s->w_col0[g]; o->len[g] = s->len[g];
+    vec = vec && s->d_col0[g] % 4 == 0 && s->w_col0[g] % 4 == 0;
+  }
+  o->vec = vec;
+  o->drop_rate = s->drop_rate; o->drop_stream = s->drop_stream; o->drop_ld = s->drop_ld; o->drop_off = s->drop_off;
+  return ASR_OK;
+}
+
+static int fill_dir(Bwd2Dir* d, const asr_rnn_step_bwd* s, int rnn_type, const uint32_t* seed) {
+  *d = Bwd2Dir{};
+  d->n_units = s->n_units;
+  int rc = fill_src(&d->src[0], &s->srcA);
+  if (rc) return rc;
+  rc = fill_src(&d->src[1], &s->srcB);
+  if (rc) return rc;
+  ASR_CHECK(!((s->srcA.drop_rate > 0.f || s->srcB.drop_rate > 0.f) && !seed), ASR_ERR_ARG, "rnn backward: dropout needs a device seed");
+  ASR_CHECK(!(s->srcA.D && s->srcA.drop_rate > 0.f), ASR_ERR_UNSUPPORTED, "rnn backward: dropout is only supported on source B");
+  d->addA = s->addA; d->addA_ld = s->addA_ld; d->addB = s->addB; d->addB_ld = s->addB_ld;
+  d->direct = s->direct; d->direct_ld = s->direct_ld; d->out = s->out; d->out_ld = s->out_ld;
+  d->dc = s->dc; d->dc_ld = s->dc_ld; d->dy_carry = s->dy_carry; d->dy_carry_ld = s->dy_carry_ld;
+  d->mask = s->mask; d->mask_ld = s->mask_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
+  d->h_prev = s->h_prev; d->h_prev_ld = s->h_prev_ld; d->c_prev = s->c_prev; d->c_prev_ld = s->c_prev_ld;
+  d->c_out = s->c_out; d->c_out_ld = s->c_out_ld; d->dslots = s->dslots; d->dslots_ld = s->dslots_ld;
+  if (!s->out) {
+    ASR_CHECK(s->saved && s->dslots, ASR_ERR_ARG, "rnn backward: saved/dslots missing");
+    ASR_CHECK(rnn_type != CELL_LSTM || (s->dc && s->c_out), ASR_ERR_ARG, "rnn backward: LSTM needs dc and c_out");
+  }
+  return ASR_OK;
+}
+
+static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st) {
+  int nu = a.d[0].n_units;
+  for (int i = 1; i < ndir; ++i) nu = a.d[i].n_units > nu ? a.d[i].n_units : nu;
+  dim3 grid((unsigned)asr_cdiv(nu, 16), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
+  dim3 block(64 * BW_NW);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_LSTM>, grid, block, 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_GRU>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_RNN>, grid, block, 0, st, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_rnn_cell_bwd(int rnn_type, int B, int ndir, const asr_rnn_step_bwd* steps, const uint32_t* seed, void* stream) {
+  ASR_CHECK(steps, ASR_ERR_ARG, "asr_rnn_cell_bwd: null argument");
+  ASR_CHECK(rnn_type >= 0 && rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", rnn_type);
+  ASR_CHECK(B > 0 && (ndir == 1 || ndir == 2), ASR_ERR_SHAPE, "asr_rnn_cell_bwd: B %d ndir %d", B, ndir);
+  Bwd2Args a{};
+  a.B = B; a.seed = seed;
+  for (int i = 0; i < ndir; ++i) {
+    ASR_CHECK(steps[i].n_units > 0, ASR_ERR_SHAPE, "asr_rnn_cell_bwd: n_units must be > 0");
+    int rc = fill_dir(&a.d[i], &steps[i], rnn_type, seed);
+    if (rc) return rc;
+  }
+  return launch_bwd(rnn_type, a, ndir, (hipStream_t)stream);
+}
+
+// column segments of the saved/dslots buffer that multiply the recurrent kernel U [H, G*H]
+static void rec_segments(int rnn_type, int H, asr_rnn_back_src* s) {
+  if (rnn_type == CELL_GRU) {
+    s->nseg = 2;
+    s->d_col0[0] = 0; s->w_col0[0] = 0; s->len[0] = 2 * H;
+    s->d_col0[1] = 3 * H; s->w_col0[1] = 2 * H; s->len[1] = H;
+  } else {
+    s->nseg = 1;
+    s->d_col0[0] = 0; s->w_col0[0] = 0; s->len[0] = (rnn_type == CELL_LSTM ? 4 : 1) * H;
+  }
+}
+
+// Whole BiRNN layer backward-through-time.  On return saved[d] holds ds (gradient wrt the gate sums)
+// for the batched dW / dU / dX GEMMs, dh0[d] the gradient wrt the initial h, dc[d] wrt the initial c.
+extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs, void* stream) {
+  ASR_CHECK(s && gs, ASR_ERR_ARG, "asr_rnn_seq_bwd: null argument");
+  ASR_CHECK(s->rnn_type >= 0 && s->rnn_type <= 2, ASR_ERR_UNSUPPORTED, "rnn_type: %d is invalid!", s->rnn_type);
+  const int B = s->B, T = s->T, H = s->H;
+  const int NS = cell_nsaved(s->rnn_type), NG = s->rnn_type == CELL_LSTM ? 4 : (s->rnn_type == CELL_GRU ? 3 : 1);
+  const bool lstm = s->rnn_type == CELL_LSTM;
+  hipStream_t st = (hipStream_t)stream;
+  for (int d = 0; d < s->ndir; ++d) {
+    ASR_CHECK(s->saved[d] && s->U[d] && gs->direct[d] && gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(!lstm || gs->dc[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: LSTM needs a dc buffer (dir %d)", d);
+    ASR_CHECK(!s->mask || gs->dy_carry[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: masked sequences need dy_carry (dir %d)", d);
+    if (hipMemsetAsync(gs->direct[d], 0, sizeof(float) * (size_t)B * H, st) != hipSuccess) { asr_set_error("asr_rnn_seq_bwd: memset failed"); return ASR_ERR_HIP; }
+  }
+  const long ld_s = (long)T * NS * H;
+  for (int step = T - 1; step >= -1; --step) {   // step == -1: gradient wrt the initial h (linear mode)
+    Bwd2Args a{};
+    a.B = B; a.seed = nullptr;
+    bool any = false;
+    for (int d = 0; d < s->ndir; ++d) {
+      const bool rev = s->reverse[d] != 0;
+      asr_rnn_step_bwd sb{};
+      sb.n_units = H;
+      const int tn_step = step + 1;                         // the step processed just before (in backward order)
+      if (tn_step <= T - 1) {
+        const int tn = rev ? T - 1 - tn_step : tn_step;
+        sb.srcA.D = s->saved[d] + (long)tn * NS * H; sb.srcA.ldd = ld_s;
+        sb.srcA.W = s->U[d]; sb.srcA.ldw = s->ldu[d] ? s->ldu[d] : (long)NG * H;
+        rec_segments(s->rnn_type, H, &sb.srcA);
+      } else {
+        sb.addA = gs->dh_last[d]; sb.addA_ld = gs->dh_last_ld[d];
+      }
+      sb.direct = gs->direct[d]; sb.direct_ld = H;
+      if (step >= 0) {
+        const int t = rev ? T - 1 - step : step;
+        const int tp = rev ? t + 1 : t - 1;
+        sb.addB = gs->dy + (long)t * gs->dy_ld + s->y_col[d]; sb.addB_ld = (long)T * gs->dy_ld;
+        sb.dc = lstm ? gs->dc[d] : nullptr; sb.dc_ld = H;
+        sb.dy_carry = s->mask ? gs->dy_carry[d] : nullptr; sb.dy_carry_ld = H;
+        sb.mask = s->mask ? s->mask + t : nullptr; sb.mask_ld = T;
+        sb.saved = s->saved[d] + (long)t * NS * H; sb.saved_ld = ld_s;
+        if (step == 0) {
+          sb.h_prev = s->h0[d]; sb.h_prev_ld = s->h0_ld[d];
+          sb.c_prev = lstm ? s->c0[d] : nullptr; sb.c_prev_ld = s->c0_ld[d];
+        } else {
+          sb.h_prev = s->hseq[d] + (long)tp * H; sb.h_prev_ld = (long)T * H;
+          sb.c_prev = lstm ? s->cseq[d] + (long)tp * H : nullptr; sb.c_prev_ld = (long)T * H;
+        }
+        sb.c_out = lstm ? s->cseq[d] + (long)t * H : nullptr; sb.c_out_ld = (long)T * H;
+        sb.dslots = s->saved[d] + (long)t * NS * H; sb.dslots_ld = ld_s;
+      } else {
+        if (!gs->dh0[d]) { sb.n_units = 0; }
+        sb.out = gs->dh0[d]; sb.out_ld = gs->dh0_ld[d];
+      }
+      if (sb.n_units > 0) {
+        int rc = fill_dir(&a.d[d], &sb, s->rnn_type, nullptr);
+        if (rc) return rc;
+        any = true;
+      } else {
+        a.d[d] = Bwd2Dir{};   // n_units == 0: every thread of that direction exits as a non-owner
+      }
+    }
+    if (!any) continue;
+    int rc = launch_bwd(s->rnn_type, a, s->ndir, st);
+    if (rc) return rc;
+  }
+  return ASR_OK;
+}

@@ -113,10 +113,9 @@ class BiRNN:
     def alloc(self, B, T, device="cuda"):
         H, rt = self.H, self.rt
         f = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
-        geom = self.cells[0].geom
         buf = dict(B=B, T=T, y=f(B, T, 2 * H), dirs=[])
         for d in range(2):
-            dd = dict(pre=f(B, T, NG[rt] * H), hseq=f(B, T, H), mtab=f(B, self.Din), slab=f(2 * ops.slab_floats(geom, B)),
+            dd = dict(pre=f(B, T, NG[rt] * H), hseq=f(B, T, H), mtab=f(B, self.Din), direct=f(B, H),
                       dy_carry=f(B, H), dh0=f(B, H), reverse=(d == 1), cell=self.cells[d])
             dd["saved"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
             if rt == "lstm":
@@ -146,6 +145,7 @@ class BiRNN:
                 ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
             ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=(b[0] if rt == "gru" else b), a_scale=dd["mtab"] if drop else None, a_rpg=T)
             dd["bias_rec"] = b[1] if rt == "gru" else None
+            dd["U"] = p[self.names[d] + "recurrent_kernel"]
             if init_states is not None:
                 st = init_states[d * nst:(d + 1) * nst]
                 dd["h0"] = st[0]
@@ -170,7 +170,7 @@ class BiRNN:
             if buf["mask"] is not None:
                 ops.fill(dd["dy_carry"], 0.0)
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
-                            dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, slab=dd["slab"], dh0=dd["dh0"]))
+                            dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"]))
         ops.rnn_seq_bwd(buf["seq"], dy3d, gds)
         x2d = buf["x3d"].reshape(B * T, self.Din)
         for d, dd in enumerate(buf["dirs"]):

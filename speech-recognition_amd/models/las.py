@@ -236,7 +236,7 @@ class LAS(ModelProto):
         ws.emb, ws.pre0 = f(U, B, Hd), f(U, B, NG[rt] * Hd)
         ws.dec = []
         for j, cell in enumerate(self.dec_cells):
-            d = dict(y=f(U, B, Hd), saved=f(U, B, NS[rt] * Hd), slab=f(2, ops.slab_floats(cell.geom, B)))
+            d = dict(y=f(U, B, Hd), saved=f(U, B, NS[rt] * Hd))
             if j < self.Ld - 1:
                 d["h"], d["c"] = f(U, B, Hd), f(U, B, Hd)
             ws.dec.append(d)
@@ -245,7 +245,7 @@ class LAS(ModelProto):
         ws.stats = torch.zeros(4, device=dev)
         # backward
         ws.dyd, ws.dctx, ws.dp, ws.ds = f(U * B, Hd), f(U, B, 2 * He), f(B, T2), f(U, B, T2)
-        ws.dh_attn, ws.dc_dec = f(B, Hd), f(B, Hd)
+        ws.dh_attn, ws.dc_dec, ws.ddirect = f(B, Hd), f(B, Hd), f(B, Hd)
         ws.xdrop = f(U * B, max(Hd, 2 * He))
         ws.demb = f(U * B, Hd)
         ws.denc, ws.dKq, ws.dK, ws.ds0 = f(B * T2, 2 * He), f(B * T2, Hd), f(B * T2, Hd), f(B * T2, 1)
@@ -478,34 +478,33 @@ class LAS(ModelProto):
                   g["attend_and_speller/feedforward/bias"], ws.dyd)
         if rate > 0:
             ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
-        # ---- decoder steps in reverse (las.py:282-288)
+        # ---- decoder steps in reverse (las.py:282-288).  Each cell hands ds (gradient wrt its gate sums,
+        # written over its saved activations) to the cells that fed it; `ws.ddirect` carries the part of
+        # dh that bypasses the gates (pad-token rows, GRU z*dh) along the single state chain.
         if rt == "lstm":
             ops.fill(ws.dc_dec, 0.0)
+        ops.fill(ws.ddirect, 0.0)
         last = self.Ld - 1
         enc3, Kq3 = ws.enc.view(B, T2, 2 * He), ws.Kq.view(B, T2, Hd)
+        dk = "attend_and_speller/decoder_layers/{}/cell/"
+        W0 = p[dk.format(0) + "kernel"]
         for i in range(U - 1, -1, -1):
             base = R.STREAM_DEC + R.DEC_STREAMS_PER_STEP * i
             for j in range(last, -1, -1):
-                cell = self.dec_cells[j]
-                geo = cell.geom
                 h_in, c_in, h_out, c_out = self._cell_states(ws, j, i)
                 st = _lib.RnnStepBwd()
-                st.KSt, st.NT, st.Wpb = geo.KSt, geo.NT, cell.Wpb.data_ptr()
-                Bpad = (B + 15) // 16 * 16
+                st.n_units = Hd
                 if j < last:      # state and output both feed layer j+1 of the same step
-                    nxt = self.dec_cells[j + 1].geom
-                    sl = ws.dec[j + 1]["slab"][i & 1]
-                    st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 16 * nxt.ks0[1]
-                    st.slabB, st.QB, st.slabB_qstride, st.slabB_ld, st.colB = sl.data_ptr(), nxt.Q, Bpad * nxt.slab_ld, nxt.slab_ld, 16 * nxt.ks0[0]
-                    st.dropB_rate, st.dropB_stream, st.dropB_ld, st.dropB_off = rate, base + 2 + j + 1, Hd, 0
+                    dn = ws.dec[j + 1]["saved"][i]
+                    st.srcA = ops.back_src(dn, p[dk.format(j + 1) + "recurrent_kernel"], rt, Hd, "rec")
+                    st.srcB = ops.back_src(dn, p[dk.format(j + 1) + "kernel"], rt, Hd, "input", (rate, base + 2 + j + 1, Hd, 0))
                 else:             # last layer: state feeds layer 0 + attention of step i+1; output feeds Dense(V)
                     if i < U - 1:
-                        g0 = self.dec_cells[0].geom
-                        sl = ws.dec[0]["slab"][(i + 1) & 1]
-                        st.slabA, st.QA, st.slabA_qstride, st.slabA_ld, st.colA = sl.data_ptr(), g0.Q, Bpad * g0.slab_ld, g0.slab_ld, 16 * g0.ks0[1]
+                        st.srcA = ops.back_src(ws.dec[0]["saved"][i + 1], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
                         st.addA, st.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
                     dyl = ws.dyd[i * B:(i + 1) * B]
                     st.addB, st.addB_ld = dyl.data_ptr(), dyl.stride(0)
+                st.direct, st.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
                 if rt == "lstm":
                     st.dc, st.dc_ld = ws.dc_dec.data_ptr(), ws.dc_dec.stride(0)
                     st.c_prev, st.c_prev_ld = c_in.data_ptr(), c_in.stride(0)
@@ -515,17 +514,22 @@ class LAS(ModelProto):
                 st.saved, st.saved_ld = sv.data_ptr(), sv.stride(0)
                 st.dslots, st.dslots_ld = sv.data_ptr(), sv.stride(0)
                 st.h_prev, st.h_prev_ld = h_in.data_ptr(), h_in.stride(0)
-                so = ws.dec[j]["slab"][i & 1]
-                st.slab_out, st.slab_out_qstride, st.slab_out_ld, st.hcol = so.data_ptr(), Bpad * geo.slab_ld, geo.slab_ld, 16 * geo.ks0[1]
-                ops.rnn_cell_bwd(rt, B, Hd, [st], seed)
-            # context gradient = layer 0's input-segment gradient through its input dropout
-            g0 = self.dec_cells[0].geom
-            ops.slab_reduce(ws.dec[0]["slab"][i & 1], g0, B, 16 * g0.ks0[0], 2 * He, ws.dctx[i], seed=seed, drop_stream=base + 2,
-                            drop_rate=rate, drop_ld=Hd + 2 * He, drop_off=Hd)
+                ops.rnn_cell_bwd(rt, B, [st], seed)
+            # context gradient = layer 0's input gradient over the context rows of its kernel, through its input dropout
+            lin = _lib.RnnStepBwd()
+            lin.n_units = 2 * He
+            lin.srcB = ops.back_src(ws.dec[0]["saved"][i], W0[Hd:], rt, Hd, "input", (rate, base + 2, Hd + 2 * He, Hd))
+            lin.out, lin.out_ld = ws.dctx[i].data_ptr(), ws.dctx[i].stride(0)
+            ops.rnn_cell_bwd(rt, B, [lin], seed)
             ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False)
         # gradient wrt the decoder's initial states (= listener state projections)
-        g0 = self.dec_cells[0].geom
-        ops.slab_reduce(ws.dec[0]["slab"][0], g0, B, 16 * g0.ks0[1], Hd, ws.dhs, add=ws.dh_attn)
+        lin = _lib.RnnStepBwd()
+        lin.n_units = Hd
+        lin.srcA = ops.back_src(ws.dec[0]["saved"][0], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
+        lin.addA, lin.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
+        lin.direct, lin.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
+        lin.out, lin.out_ld = ws.dhs.data_ptr(), ws.dhs.stride(0)
+        ops.rnn_cell_bwd(rt, B, [lin], None)
         # ---- decoder weight gradients, batched over steps
         for j in range(self.Ld):
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"

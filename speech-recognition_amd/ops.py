@@ -153,7 +153,6 @@ class PackedCell:
         self.rnn_type, self.H, self.Ks = rnn_type, H, list(Ks)
         self.geom = rnn_geometry(rnn_type, H, Ks)
         self.Wp = torch.empty(self.geom.wp_floats, device=device, dtype=torch.float32)
-        self.Wpb = torch.empty(self.geom.wpb_floats, device=device, dtype=torch.float32)
 
     def pack(self, weights):
         n = len(weights)
@@ -165,7 +164,7 @@ class PackedCell:
         for (w, _), k in zip(weights, self.Ks):
             _dev(w, name="weight")
             assert w.shape[0] == k and w.stride(1) == 1
-        check(lib().asr_rnn_pack(rnn_type_id(self.rnn_type), self.H, n, Wp, ld, K, rec, _p(self.Wp), _p(self.Wpb), _stream()))
+        check(lib().asr_rnn_pack(rnn_type_id(self.rnn_type), self.H, n, Wp, ld, K, rec, _p(self.Wp), _stream()))
         return self
 
 
@@ -183,7 +182,8 @@ def make_rnn_seq(rnn_type, B, T, H, dirs, mask, y, y_cols):
     s.reverse = (C.c_int * 2)(*([int(d.get("reverse", False)) for d in dirs] + [0] * (2 - len(dirs))))
     s.pre = _arr2([d["pre"] for d in dirs])
     s.Wp = _arr2([d["cell"].Wp for d in dirs])
-    s.Wpb = _arr2([d["cell"].Wpb for d in dirs])
+    s.U = _arr2([d.get("U") for d in dirs])
+    s.ldu = _arr2([d["U"].stride(0) if d.get("U") is not None else 0 for d in dirs], C.c_long)
     s.bias_rec = _arr2([d.get("bias_rec") for d in dirs])
     s.h0 = _arr2([d.get("h0") for d in dirs])
     s.h0_ld = _arr2([d["h0"].stride(0) if d.get("h0") is not None else 0 for d in dirs], C.c_long)
@@ -205,7 +205,7 @@ def rnn_seq_fwd(seq):
 
 
 def rnn_seq_bwd(seq, dy, dirs_grad):
-    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, slab, dh0."""
+    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0."""
     g = _lib.RnnSeqGrad()
     g.dy = dy.data_ptr()
     g.dy_ld = dy.stride(1)
@@ -213,23 +213,33 @@ def rnn_seq_bwd(seq, dy, dirs_grad):
     g.dh_last_ld = _arr2([d["dh_last"].stride(0) if d.get("dh_last") is not None else 0 for d in dirs_grad], C.c_long)
     g.dc = _arr2([d.get("dc") for d in dirs_grad])
     g.dy_carry = _arr2([d.get("dy_carry") for d in dirs_grad])
-    g.slab = _arr2([d["slab"] for d in dirs_grad])
+    g.direct = _arr2([d["direct"] for d in dirs_grad])
     g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
     g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
     check(lib().asr_rnn_seq_bwd(C.byref(seq), C.byref(g), _stream()))
 
 
-def slab_floats(geom, B):
-    return geom.Q * ((B + 15) // 16 * 16) * geom.slab_ld
-
-
-def slab_reduce(slab, geom, B, col0, ncols, out, add=None, accumulate=False, seed=None, drop_stream=0, drop_rate=0.0,
-                drop_ld=0, drop_off=0):
-    Bpad = (B + 15) // 16 * 16
-    check(lib().asr_slab_reduce(_p(slab), geom.Q, Bpad * geom.slab_ld, geom.slab_ld, col0, ncols, B, _p(add),
-                                add.stride(0) if add is not None else 0, _p(out), out.stride(0), int(accumulate),
-                                _p(seed) if drop_rate > 0 else None, drop_stream, float(drop_rate), drop_ld, drop_off, _stream()))
-    return out
+def back_src(D, W, rnn_type, H, kind, drop=None):
+    """asr_rnn_back_src for a consumer whose ds rows are D ([B, NS*H] view) and whose Keras kernel is W
+    (rows = the units / input features receiving the gradient).  kind: 'rec' (recurrent kernel: the
+    consumer read this cell's state) or 'input' (input kernel: it read this cell's output).
+    drop: (rate, stream, ld, off) of the consumer's input dropout or None."""
+    s = _lib.RnnBackSrc()
+    s.D, s.ldd, s.W, s.ldw = D.data_ptr(), D.stride(0), W.data_ptr(), W.stride(0)
+    if rnn_type == "gru":
+        if kind == "rec":
+            s.nseg = 2
+            s.d_col0[0], s.w_col0[0], s.len[0] = 0, 0, 2 * H
+            s.d_col0[1], s.w_col0[1], s.len[1] = 3 * H, 2 * H, H
+        else:
+            s.nseg = 1
+            s.d_col0[0], s.w_col0[0], s.len[0] = 0, 0, 3 * H
+    else:
+        s.nseg = 1
+        s.d_col0[0], s.w_col0[0], s.len[0] = 0, 0, (4 if rnn_type == "lstm" else 1) * H
+    if drop is not None and drop[0] > 0:
+        s.drop_rate, s.drop_stream, s.drop_ld, s.drop_off = drop
+    return s
 
 
 # ----------------------------------------------------------------------------------------- cells (decoder steps)
@@ -239,9 +249,9 @@ def rnn_cell_fwd(rnn_type, B, H, steps, seed=None):
     check(lib().asr_rnn_cell_fwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _p(seed), _stream()))
 
 
-def rnn_cell_bwd(rnn_type, B, H, steps, seed=None):
+def rnn_cell_bwd(rnn_type, B, steps, seed=None):
     arr = (_lib.RnnStepBwd * len(steps))(*steps)
-    check(lib().asr_rnn_cell_bwd(rnn_type_id(rnn_type), B, H, len(steps), arr, _p(seed), _stream()))
+    check(lib().asr_rnn_cell_bwd(rnn_type_id(rnn_type), B, len(steps), arr, _p(seed), _stream()))
 
 
 def token_mask(tok, pad, out):

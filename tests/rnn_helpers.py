@@ -26,8 +26,9 @@ class HipBiRNN:
         for d, (W, U, b) in enumerate(self.params):
             b_in = b[0] if rnn_type == "gru" else b
             pre = gpu((x.double() @ W.double() + b_in.double()).float())
-            cell = ops.PackedCell(rnn_type, H, [H]).pack([(gpu(U), True)])
-            dd = dict(pre=pre, cell=cell, reverse=(d == 1), hseq=torch.zeros(B, T, H, device="cuda"),
+            Ug = gpu(U)
+            cell = ops.PackedCell(rnn_type, H, [H]).pack([(Ug, True)])
+            dd = dict(pre=pre, cell=cell, U=Ug, reverse=(d == 1), hseq=torch.zeros(B, T, H, device="cuda"),
                       saved=torch.zeros(B, T, ns * H, device="cuda"))
             if rnn_type == "lstm":
                 dd["cseq"] = torch.zeros(B, T, H, device="cuda")
@@ -55,11 +56,10 @@ class HipBiRNN:
         """dy [B,T,ndir*H]; dstates: list like the states list (or None entries). Returns dict of grads."""
         ops, B, T, H = self.ops, self.B, self.T, self.H
         nst = 2 if self.rt == "lstm" else 1
-        geom = self.dirs[0]["cell"].geom
         gds = []
         for d, dd in enumerate(self.dirs):
             st = dstates[d * nst:(d + 1) * nst]
-            g = dict(slab=torch.zeros(2 * ops.slab_floats(geom, B), device="cuda"),
+            g = dict(direct=torch.zeros(B, H, device="cuda"),
                      dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"))
             if st[0] is not None:
                 g["dh_last"] = gpu(st[0])

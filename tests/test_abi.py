@@ -38,4 +38,4 @@ def test_bad_arguments_fail_without_touching_the_gpu():
     assert lib.asr_rnn_geometry(7, 8, 1, arr, ctypes.byref(g)) == -3
     assert b"rnn_type" in lib.asr_last_error()
     assert lib.asr_rnn_geometry(0, 10, 1, arr, ctypes.byref(g)) == 0
-    assert (g.Q, g.KSt, g.NT, g.slab_ld) == (3, 1, 1, 16)
+    assert (g.Q, g.KSt, g.wp_floats) == (3, 1, 768)
