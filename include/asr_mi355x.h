@@ -297,6 +297,14 @@ typedef struct asr_rnn_seq {
   float* saved[2];
 } asr_rnn_seq;
 int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream);
+/* The same layer forward as ONE persistent launch (workgroups stay resident over all T steps and hand
+ * h_t to each other through global memory; every spin is bounded).  Supported when H % 16 == 0,
+ * H <= 256, T >= 2 and ceil(H/4) * ceil(B/16) * ndir <= 256 workgroups.  ws: scratch of
+ * asr_rnn_persist_ws_floats() floats; word [ws_floats - 32] (as uint32) is non-zero after the call if a
+ * hand-off timed out (results invalid - rerun with asr_rnn_seq_fwd). */
+long asr_rnn_persist_ws_floats(int B, int H, int ndir);
+int asr_rnn_persist_supported(int rnn_type, int B, int T, int H, int ndir);
+int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* stream);
 
 typedef struct asr_rnn_seq_grad {
   const float* dy; long dy_ld;              /* gradient wrt y, same layout as y                      */
@@ -308,6 +316,12 @@ typedef struct asr_rnn_seq_grad {
 } asr_rnn_seq_grad;
 /* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs. */
 int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* stream);
+/* The same backward-through-time as ONE persistent launch (results equal to fp32 rounding; g->direct and
+ * g->dy_carry are unused).  Supported when H % 16 == 0, G*H <= 1024, T >= 2 and
+ * ceil(H/16) * ceil(B/16) * ndir <= 256 workgroups.  ws / error word as for asr_rnn_seq_fwd_persist. */
+long asr_rnn_persist_bwd_ws_floats(int B, int H, int ndir);
+int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
+int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,12 @@ SIGNATURES = {
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),
+    "asr_rnn_persist_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_persist_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_seq_fwd_persist": (C.c_int, [C.POINTER(RnnSeq), _P, _P]),
+    "asr_rnn_persist_bwd_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_persist_bwd_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_seq_bwd_persist": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P, _P]),
     "asr_conv2d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asr_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_uint32, C.c_float, _P]),
     "asr_conv2d_bwd_filter": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

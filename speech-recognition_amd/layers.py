@@ -14,6 +14,11 @@ import torch
 from . import ops
 from . import rng as R
 
+import os
+
+# ASR_PERSISTENT_RNN=0 forces the one-launch-per-step recurrent kernels (debugging / A-B timing)
+PERSISTENT_RNN = os.environ.get("ASR_PERSISTENT_RNN", "1") != "0"
+
 NG = {"lstm": 4, "gru": 3, "rnn": 1}   # gates in the Keras kernel layout
 NS = {"lstm": 4, "gru": 4, "rnn": 1}   # columns saved per unit by the cell kernels ("slots")
 
@@ -156,7 +161,13 @@ class BiRNN:
         buf["x3d"] = x3d
         buf["drop"] = drop
         buf["seq"] = ops.make_rnn_seq(rt, B, T, H, buf["dirs"], mask, buf["y"], [0, H])
-        ops.rnn_seq_fwd(buf["seq"])
+        # one persistent launch for all T steps when the layer fits on the chip, else one launch per step
+        if PERSISTENT_RNN and ops.rnn_persist_supported(rt, B, T, H, 2):
+            if "persist_ws" not in buf:
+                buf["persist_ws"] = ops.rnn_persist_ws(B, H, 2, x3d.device)
+            ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"])
+        else:
+            ops.rnn_seq_fwd(buf["seq"])
         return buf["y"]
 
     def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False):
@@ -171,7 +182,12 @@ class BiRNN:
                 ops.fill(dd["dy_carry"], 0.0)
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
                             dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"]))
-        ops.rnn_seq_bwd(buf["seq"], dy3d, gds)
+        pws = None
+        if PERSISTENT_RNN and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
+            if "persist_bwd_ws" not in buf:
+                buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
+            pws = buf["persist_bwd_ws"]
+        ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws)
         x2d = buf["x3d"].reshape(B * T, self.Din)
         for d, dd in enumerate(buf["dirs"]):
             g, p = self.store.g, self.store.p

@@ -204,8 +204,27 @@ def rnn_seq_fwd(seq):
     check(lib().asr_rnn_seq_fwd(C.byref(seq), _stream()))
 
 
-def rnn_seq_bwd(seq, dy, dirs_grad):
-    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0."""
+def rnn_persist_supported(rnn_type, B, T, H, ndir=2):
+    return bool(lib().asr_rnn_persist_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+
+
+def rnn_persist_ws(B, H, ndir=2, device="cuda"):
+    return torch.zeros(int(lib().asr_rnn_persist_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
+
+
+def rnn_seq_fwd_persist(seq, ws):
+    """One persistent launch for the whole sequence; ws from rnn_persist_ws (error word = ws[-32] bits)."""
+    check(lib().asr_rnn_seq_fwd_persist(C.byref(seq), _p(ws), _stream()))
+
+
+def rnn_persist_error(ws) -> bool:
+    """True if a hand-off of the last persistent launch timed out (synchronises)."""
+    return bool(ws[-32:].view(torch.int32)[0].item() != 0)
+
+
+def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None):
+    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0.
+    persist_ws: scratch from rnn_persist_bwd_ws -> one persistent launch instead of one per step."""
     g = _lib.RnnSeqGrad()
     g.dy = dy.data_ptr()
     g.dy_ld = dy.stride(1)
@@ -213,10 +232,21 @@ def rnn_seq_bwd(seq, dy, dirs_grad):
     g.dh_last_ld = _arr2([d["dh_last"].stride(0) if d.get("dh_last") is not None else 0 for d in dirs_grad], C.c_long)
     g.dc = _arr2([d.get("dc") for d in dirs_grad])
     g.dy_carry = _arr2([d.get("dy_carry") for d in dirs_grad])
-    g.direct = _arr2([d["direct"] for d in dirs_grad])
+    g.direct = _arr2([d.get("direct") for d in dirs_grad])
     g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
     g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
-    check(lib().asr_rnn_seq_bwd(C.byref(seq), C.byref(g), _stream()))
+    if persist_ws is not None:
+        check(lib().asr_rnn_seq_bwd_persist(C.byref(seq), C.byref(g), _p(persist_ws), _stream()))
+    else:
+        check(lib().asr_rnn_seq_bwd(C.byref(seq), C.byref(g), _stream()))
+
+
+def rnn_persist_bwd_supported(rnn_type, B, T, H, ndir=2):
+    return bool(lib().asr_rnn_persist_bwd_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+
+
+def rnn_persist_bwd_ws(B, H, ndir=2, device="cuda"):
+    return torch.zeros(int(lib().asr_rnn_persist_bwd_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
 
 
 def back_src(D, W, rnn_type, H, kind, drop=None):

@@ -42,8 +42,14 @@ class HipBiRNN:
             self.dirs.append(dd)
         self.seq = ops.make_rnn_seq(rnn_type, B, T, H, self.dirs, self.mask, self.y, [d * H for d in range(ndir)])
 
-    def forward(self):
-        self.ops.rnn_seq_fwd(self.seq)
+    def forward(self, persistent=False):
+        if persistent:
+            assert self.ops.rnn_persist_supported(self.rt, self.B, self.T, self.H, len(self.dirs))
+            ws = self.ops.rnn_persist_ws(self.B, self.H, len(self.dirs))
+            self.ops.rnn_seq_fwd_persist(self.seq, ws)
+            assert not self.ops.rnn_persist_error(ws), "persistent kernel: a hand-off timed out"
+        else:
+            self.ops.rnn_seq_fwd(self.seq)
         states = []
         for d, dd in enumerate(self.dirs):
             t_last = 0 if dd["reverse"] else self.T - 1
@@ -52,7 +58,7 @@ class HipBiRNN:
                 states.append(dd["cseq"][:, t_last])
         return self.y, states
 
-    def backward(self, dy, dstates):
+    def backward(self, dy, dstates, persistent=False):
         """dy [B,T,ndir*H]; dstates: list like the states list (or None entries). Returns dict of grads."""
         ops, B, T, H = self.ops, self.B, self.T, self.H
         nst = 2 if self.rt == "lstm" else 1
@@ -66,7 +72,13 @@ class HipBiRNN:
             if self.rt == "lstm":
                 g["dc"] = gpu(st[1]) if st[1] is not None else torch.zeros(B, H, device="cuda")
             gds.append(g)
-        ops.rnn_seq_bwd(self.seq, gpu(dy), gds)
+        pws = None
+        if persistent:
+            assert ops.rnn_persist_bwd_supported(self.rt, B, T, H, len(self.dirs))
+            pws = ops.rnn_persist_bwd_ws(B, H, len(self.dirs))
+        ops.rnn_seq_bwd(self.seq, gpu(dy), gds, pws)
+        if persistent:
+            assert not ops.rnn_persist_error(pws), "persistent backward: a hand-off timed out"
         out = []
         for d, (dd, g) in enumerate(zip(self.dirs, gds)):
             W, U, b = [p.double() for p in self.params[d]]

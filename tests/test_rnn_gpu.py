@@ -89,3 +89,58 @@ def test_invalid_rnn_type_raises_value_error():
     from speech_recognition_amd import ops
     with pytest.raises(ValueError, match="rnn_type: foo is invalid!"):
         ops.rnn_geometry("foo", 8, [8])
+
+
+PERSIST_CASES = [("lstm", 32, 40, 16, 256), ("gru", 20, 12, 7, 128), ("rnn", 5, 6, 3, 16), ("lstm", 7, 25, 4, 48), ("lstm", 32, 249, 8, 256)]
+
+
+@pytest.mark.parametrize("rt,B,T,D,H", PERSIST_CASES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_persistent_forward_matches_oracle_and_step_kernels(rt, B, T, D, H, masked):
+    """The one-launch persistent layer kernel (in-kernel hand-offs of h_t) against the oracle and,
+    bit for bit, against the per-step kernels (same arithmetic order)."""
+    g = torch.Generator().manual_seed(B + T + H)
+    fwd, bwd = make_params(rt, D, H, g, 0.3 if H < 100 else 0.08)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = (torch.randn(B, T, generator=g) > -0.3) if masked else torch.ones(B, T, dtype=torch.bool)
+    nst = 2 if rt == "lstm" else 1
+    init = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.5 for _ in range(2 * nst)] if masked else None
+    out, *states = L.birnn(rt, x, mask, fwd, bwd, init)
+    hip = HipBiRNN(rt, x, mask if masked else None, fwd, bwd, init)
+    y, hstates = hip.forward(persistent=True)
+    y, hstates = y.clone(), [s.clone() for s in hstates]
+    assert_close(y, out, 1e-4, "outputs")
+    for i, (a, b_) in enumerate(zip(hstates, states)):
+        assert_close(a, b_, 1e-4, f"state {i}")
+    hip2 = HipBiRNN(rt, x, mask if masked else None, fwd, bwd, init)
+    y2, hstates2 = hip2.forward(persistent=False)
+    assert torch.equal(y, y2)
+    for a, b_ in zip(hstates, hstates2):
+        assert torch.equal(a, b_)
+    for da, db in zip(hip.dirs, hip2.dirs):
+        assert torch.equal(da["saved"], db["saved"]) and torch.equal(da["hseq"], db["hseq"])
+
+
+@pytest.mark.parametrize("rt,B,T,D,H", PERSIST_CASES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_persistent_backward_matches_step_kernels(rt, B, T, D, H, masked):
+    """Same algorithm and summation order as the per-step kernels; results agree to fp32 rounding (the
+    compiler contracts the gate-gradient expressions differently in the two kernels)."""
+    g = torch.Generator().manual_seed(B + 3 * T + H)
+    fwd, bwd = make_params(rt, D, H, g, 0.3 if H < 100 else 0.08)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = (torch.randn(B, T, generator=g) > -0.3) if masked else None
+    nst = 2 if rt == "lstm" else 1
+    init = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.5 for _ in range(2 * nst)] if masked else None
+    R = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64)
+    S = [torch.randn(B, H, generator=g, dtype=torch.float64) for _ in range(2 * nst)]
+    res = []
+    for persistent in (False, True):
+        hip = HipBiRNN(rt, x, mask, fwd, bwd, init)
+        hip.forward(persistent=persistent)
+        grads = hip.backward(R, S, persistent=persistent)
+        res.append((grads, [dd["saved"].clone() for dd in hip.dirs]))
+    for d in range(2):
+        assert_close(res[1][1][d], res[0][1][d], 2e-5, "ds")
+        for k in res[0][0][d]:
+            assert_close(res[1][0][d][k], res[0][0][d][k], 2e-5, k)
