@@ -4,17 +4,17 @@
 // launch, kernel-argument fetch, end-of-kernel write-back), not the 0.3 us of MFMA work.  Here the
 // workgroups of a (direction, 16-row batch tile) group stay resident, keep their slice of the
 // recurrent kernel in registers for the whole sequence, and hand h_t to each other through global
-// memory with the placement-independent protocol of cdna_hip_programming.md Guideline 16 (table row
-// "agent-scope atomic adds + sc1 poll + workgroup barrier + sc1 stores / sc1 dwordx4 loads"):
-//   producer: every workgroup writes its 16 x 4 slice of h_t as ONE 256-byte wave store (two whole
-//             128-B lines, write-through `sc1`) into an exchange buffer, waits `vmcnt(0)`, then
-//             lane 0 does a relaxed agent-scope atomic add on the group's counter;
-//   consumer: one lane polls the counter (relaxed agent-scope = `sc1` load) until all Q workgroups of
-//             the group have published step s-1, workgroup barrier, then every wave reads the 16 x H
-//             slab of h_{t-1} with `global_load_dwordx4 ... sc1` (bypasses this CU's L1).
-// The exchange buffer is double-buffered by step parity: a workgroup can only be one step ahead of
-// the slowest member of its group.  Every spin is bounded: on time-out the workgroup raises the
-// error word and leaves, the others follow one time-out later; the host falls back to / reports.
+// memory with data-tagged granules (cdna_hip_programming.md Guideline 16, recipe R2: "the data IS the
+// flag"): every value travels as one naturally aligned 8-byte {value, tag = step + 1} granule written
+// by ONE write-through (`sc1`) store - no separate flag, no fence, no drain.
+//   producer: wave 0 of every workgroup stores its 16 x 4 slice of h_t as one 512-byte wave store
+//             (`global_store_dwordx2 ... sc1`, four whole 128-B lines);
+//   consumer: every wave re-reads the granules it needs (`global_load_dwordx4 ... sc1`, two granules
+//             per load, bypassing this CU's L1) until all their tags equal the step it waits for.
+// The exchange buffer is double-buffered by step parity (a workgroup can be at most one step ahead of
+// the slowest member of its group) and zeroed before every launch, so a stale or never-written
+// granule can never carry the awaited tag.  Every spin is bounded: on time-out the workgroup raises
+// the error word and leaves, the others follow one time-out later.
 // Residency: grid = Q x (B/16) x ndir workgroups of 256 threads, required <= 256 (one per CU).
 #include "common.h"
 
@@ -22,6 +22,7 @@
 #define CELL_GRU 1
 #define CELL_RNN 2
 #define PS_MAXB 4      // K blocks per wave held in registers: H <= 16 * 4 * PS_MAXB = 256
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct PDir {
   const float* pre; const float* Wp; const float* bias_rec;
@@ -34,24 +35,14 @@ struct PArgs {
   int B, T, H, KB;
   const uint8_t* mask;
   float* y; long y_ld;
-  float* xbuf;          // [groups][2][Q][16][4] exchange buffer
-  unsigned* counters;   // [groups] * 32 words apart
+  float* xbuf;          // [groups][2][Q][16 rows][4 units] granules of 2 floats {value, tag}
   unsigned* err;
   int spin_limit;
 };
 
-__device__ __forceinline__ bool ps_wait(unsigned* c, unsigned target, int limit) {
-  for (int i = 0; i < limit; ++i) {
-    const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >= target) return true;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return false;
-}
-
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
-  __shared__ float part[4][16 * 17];
+  __shared__ float part[2][4][16 * 17];
   __shared__ int abort_flag;
   const PDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,8 +50,7 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
   const int q = blockIdx.x, b0 = blockIdx.y * 16, Q = gridDim.x;
   const int B = a.B, T = a.T, H = a.H;
   const int group = blockIdx.z * gridDim.y + blockIdx.y;
-  unsigned* counter = a.counters + group * 32;
-  float* xb = a.xbuf + (long)group * 2 * Q * 64;
+  float* xb = a.xbuf + (long)group * 2 * Q * 128;        // 128 floats = 64 granules per workgroup and parity
   constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
   constexpr int NS = CELL == CELL_RNN ? 1 : 4;
 
@@ -71,6 +61,13 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
   for (int i = 0; i < PS_MAXB; ++i) {
     const int jb = wave + 4 * i;
     bw[i] = jb < a.KB ? wp[(long)jb * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // granule addresses of this lane's operands: block jb -> workgroup 4jb+lq, row li, units 0..3 = 8 floats
+  int goff[PS_MAXB];
+#pragma unroll
+  for (int i = 0; i < PS_MAXB; ++i) {
+    const int jb = wave + 4 * i;
+    goff[i] = jb < a.KB ? ((4 * jb + lq) * 16 + li) * 8 : -1;
   }
   // gate-math ownership (wave 0): lane -> (row bi, unit u); recurrent state lives in registers
   const int bi = lane >> 2, u = lane & 3;
@@ -98,58 +95,70 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) pre[g] = pr[(long)g * H];
     }
-    // wait for h_{s-1} of the whole group
-    if (s > 0 && wave == 1 && lane == 0) {
-      if (!ps_wait(counter, (unsigned)Q * (unsigned)s, a.spin_limit)) abort_flag = 1;
-    }
-    __syncthreads();
-    if (abort_flag) break;
 
     // A operand: 16 rows x H of h_{s-1}
-    f32x4 av[PS_MAXB];
+    float av[PS_MAXB][4];
     if (s == 0) {
 #pragma unroll
       for (int i = 0; i < PS_MAXB; ++i) {
         const int jb = wave + 4 * i;
-        av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[i][e] = 0.f;
         if (jb < a.KB && d.h0 != nullptr && b0 + li < B) {
           const float* hr = d.h0 + (long)(b0 + li) * d.h0_ld + 16 * jb + 4 * lq;
-          av[i] = (f32x4){hr[0], hr[1], hr[2], hr[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[i][e] = hr[e];
         }
       }
     } else {
-      // exchange layout [Q][16 rows][4 units]: the float4 of (row li, units 16jb+4lq..+3) is workgroup 4jb+lq's
-      const float* src = xb + (long)((s - 1) & 1) * Q * 64;
-      const float* p0 = src + ((long)(4 * (wave + 0) + lq) * 16 + li) * 4;
-      const float* p1 = src + ((long)(4 * (wave + 4) + lq) * 16 + li) * 4;
-      const float* p2 = src + ((long)(4 * (wave + 8) + lq) * 16 + li) * 4;
-      const float* p3 = src + ((long)(4 * (wave + 12) + lq) * 16 + li) * 4;
-      // blocks beyond KB alias block 0 of this wave (valid memory); their weights are zero
-      if (wave + 4 >= a.KB) p1 = p0;
-      if (wave + 8 >= a.KB) p2 = p0;
-      if (wave + 12 >= a.KB) p3 = p0;
-      if (wave >= a.KB) { p0 = src; p1 = src; p2 = src; p3 = src; }
-      asm volatile(
-          "global_load_dwordx4 %0, %4, off sc1\n\t"
-          "global_load_dwordx4 %1, %5, off sc1\n\t"
-          "global_load_dwordx4 %2, %6, off sc1\n\t"
-          "global_load_dwordx4 %3, %7, off sc1\n\t"
-          "s_waitcnt vmcnt(0)"
-          : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3])
-          : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-          : "memory");
+      const float* src = xb + (long)((s - 1) & 1) * Q * 128;
+      const float* p[PS_MAXB];
+#pragma unroll
+      for (int i = 0; i < PS_MAXB; ++i) p[i] = src + (goff[i] >= 0 ? goff[i] : 0);
+      const unsigned want = (unsigned)s;               // tag of the data published at step s-1
+      f32x4 g0, g1, g2, g3, g4, g5, g6, g7;
+      int spins = 0;
+      for (;;) {
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\t"
+            "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %2, %9, off sc1\n\t"
+            "global_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %4, %10, off sc1\n\t"
+            "global_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+            "global_load_dwordx4 %6, %11, off sc1\n\t"
+            "global_load_dwordx4 %7, %11, off offset:16 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7)
+            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+            : "memory");
+        bool ok = true;
+        if (goff[0] >= 0) ok = ok && __float_as_uint(g0.y) == want && __float_as_uint(g0.w) == want && __float_as_uint(g1.y) == want && __float_as_uint(g1.w) == want;
+        if (goff[1] >= 0) ok = ok && __float_as_uint(g2.y) == want && __float_as_uint(g2.w) == want && __float_as_uint(g3.y) == want && __float_as_uint(g3.w) == want;
+        if (goff[2] >= 0) ok = ok && __float_as_uint(g4.y) == want && __float_as_uint(g4.w) == want && __float_as_uint(g5.y) == want && __float_as_uint(g5.w) == want;
+        if (goff[3] >= 0) ok = ok && __float_as_uint(g6.y) == want && __float_as_uint(g6.w) == want && __float_as_uint(g7.y) == want && __float_as_uint(g7.w) == want;
+        if (__all(ok)) break;
+        if (++spins > a.spin_limit || *(volatile int*)&abort_flag) { abort_flag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      av[0][0] = g0.x; av[0][1] = g0.z; av[0][2] = g1.x; av[0][3] = g1.z;
+      av[1][0] = g2.x; av[1][1] = g2.z; av[1][2] = g3.x; av[1][3] = g3.z;
+      av[2][0] = g4.x; av[2][1] = g4.z; av[2][2] = g5.x; av[2][3] = g5.z;
+      av[3][0] = g6.x; av[3][1] = g6.z; av[3][2] = g7.x; av[3][3] = g7.z;
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < PS_MAXB; ++i) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bw[i].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bw[i].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bw[i].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bw[i].w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][0], bw[i].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][1], bw[i].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][2], bw[i].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][3], bw[i].w, acc, 0, 0, 0);
     }
+    float(*pt)[16 * 17] = part[s & 1];                 // double-buffered: a wave may run one step ahead of wave 0
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave][(lq * 4 + r) * 17 + li] = acc[r];
+    for (int r = 0; r < 4; ++r) pt[wave][(lq * 4 + r) * 17 + li] = acc[r];
     __syncthreads();
+    if (abort_flag) break;
 
     if (wave == 0) {
       float hnew = hp;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
         float sg[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          sg[g] = part[0][bi * 17 + g * 4 + u] + part[1][bi * 17 + g * 4 + u] + part[2][bi * 17 + g * 4 + u] + part[3][bi * 17 + g * 4 + u];
+          sg[g] = pt[0][bi * 17 + g * 4 + u] + pt[1][bi * 17 + g * 4 + u] + pt[2][bi * 17 + g * 4 + u] + pt[3][bi * 17 + g * 4 + u];
         float hn, cn = cp;
         float* sv = d.saved ? d.saved + ((long)b * T + t) * NS * H + j : nullptr;
         if (CELL == CELL_LSTM) {
@@ -183,22 +192,26 @@ __global__ __launch_bounds__(256) void rnn_seq_fwd_persist_kernel(PArgs a) {
         yp = m ? hn : yp;
         cp = cn;
         hp = hnew;
+      }
+      // publish the 16 x 4 slice first (it is on every other workgroup's critical path): one 512-byte wave
+      // store of {value, tag} granules, lane = row*4 + unit
+      float* dst = xb + (long)(s & 1) * Q * 128 + (long)q * 128 + lane * 2;
+      const float tagf = __uint_as_float((unsigned)(s + 1));
+      f32x2 gran = {hnew, tagf};
+      asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(gran) : "memory");
+      if (live) {
         d.hseq[((long)b * T + t) * H + j] = hnew;
         a.y[((long)b * T + t) * a.y_ld + d.y_col + j] = yp;
       }
-      // publish this workgroup's 16 x 4 slice: ONE 256-byte wave store (lane = row*4 + unit), then signal
-      float* dst = xb + (long)(s & 1) * Q * 64 + (long)q * 64 + lane;
-      asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dst), "v"(hnew) : "memory");
-      if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (abort_flag && tid == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// scratch the caller provides: exchange buffer + counters + error word (floats)
+// scratch the caller provides: granule exchange buffer + error word (floats)
 extern "C" long asr_rnn_persist_ws_floats(int B, int H, int ndir) {
   const long groups = (long)ndir * asr_cdiv(B, 16), Q = asr_cdiv(H, 4);
-  return groups * 2 * Q * 64 + groups * 32 + 32;
+  return groups * 2 * Q * 128 + 32;
 }
 
 // 1 when the persistent kernel can run this layer (otherwise use asr_rnn_seq_fwd)
@@ -217,12 +230,12 @@ extern "C" int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* st
   const bool lstm = s->rnn_type == CELL_LSTM;
   hipStream_t st = (hipStream_t)stream;
   const long groups = (long)s->ndir * asr_cdiv(B, 16), Q = asr_cdiv(H, 4);
+  const long ws_floats = groups * 2 * Q * 128 + 32;
   PArgs a{};
   a.B = B; a.T = T; a.H = H; a.KB = asr_cdiv(H, 16);
   a.mask = s->mask; a.y = s->y; a.y_ld = s->y_ld;
   a.xbuf = ws;
-  a.counters = reinterpret_cast<unsigned*>(ws + groups * 2 * Q * 64);
-  a.err = a.counters + groups * 32;
+  a.err = reinterpret_cast<unsigned*>(ws + ws_floats - 32);
   a.spin_limit = 1 << 20;
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_seq_fwd_persist: null buffer (dir %d)", d);
@@ -233,8 +246,8 @@ extern "C" int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* st
     p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
   }
-  // counters + error word are zeroed on every call (a memset node when captured)
-  if (hipMemsetAsync(a.counters, 0, sizeof(unsigned) * (groups * 32 + 32), st) != hipSuccess) { asr_set_error("asr_rnn_seq_fwd_persist: memset failed"); return ASR_ERR_HIP; }
+  // every tag and the error word are zeroed on every call (a memset node when captured)
+  if (hipMemsetAsync(ws, 0, sizeof(float) * ws_floats, st) != hipSuccess) { asr_set_error("asr_rnn_seq_fwd_persist: memset failed"); return ASR_ERR_HIP; }
   dim3 grid((unsigned)Q, (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
   if (s->rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_seq_fwd_persist_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
   else if (s->rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_seq_fwd_persist_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);

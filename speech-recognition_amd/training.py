@@ -170,6 +170,13 @@ class TrainStep:
             self.exchange.comm_stream.synchronize()
 
     def read_stats(self, ws):
-        """Host copy of [loss, #correct, #kept] (synchronises)."""
+        """Host copy of [loss, #correct, #kept] (synchronises).  Also checks the error words of the
+        persistent recurrent kernels: a timed-out hand-off invalidates the step and is never silent."""
         self.synchronize()
+        for lw in getattr(ws, "layers", []):
+            for key in ("persist_ws", "persist_bwd_ws"):
+                pws = lw["rnn"].get(key) if isinstance(lw, dict) and "rnn" in lw else None
+                if pws is not None and ops.rnn_persist_error(pws):
+                    raise RuntimeError("persistent recurrent kernel: an inter-workgroup hand-off timed out "
+                                       "(GPU shared with another job?); rerun with ASR_PERSISTENT_RNN=0")
         return [float(v) for v in ws.stats[:3].cpu()]
