@@ -64,6 +64,18 @@ int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio, const int
                         const float* twiddle, const float* melw, const int32_t* melrange, const uint32_t* seed,
                         float* out, int T_out, void* stream);
 
+/* The same SpecAugment and delta steps as stand-alone kernels on feature tensors, for batches that
+ * arrive as stored features (run/train.py:70-74 --use-tfrecord) instead of raw audio.
+ * asr_spec_augment (data.py:282-301): x [B, T, v, C] is masked IN PLACE with 0.0; n_frames [B] int32
+ * (device, NULL = T for every clip) is the reference's num_time of each clip; the draws are those of
+ * asr_logmel_features for the same seed, so both routes zero the same bands.  Only the sa_* fields
+ * and num_mel_bins (= v) of cfg are read.
+ * asr_delta_accelerate (data.py:310-328): x [B, T, v] -> out [B, T, v, 3] = (x, delta, delta-delta)
+ * with x[-1] = 0; frames t >= n_frames[b] are written as exact 0.0 (padding stays padding). */
+int asr_spec_augment(const asr_logmel_cfg* cfg, float* x, const int32_t* n_frames, int B, int T, int C,
+                     const uint32_t* seed, void* stream);
+int asr_delta_accelerate(const float* x, const int32_t* n_frames, int B, int T, int v, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense contraction (tf.matmul / Dense / the batched halves of LSTM, attention and vocab
  * projections: las.py:43-59,169,193,196-202,264; deepspeech2.py:177; and every weight/input
@@ -322,6 +334,27 @@ int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* strea
 long asr_rnn_persist_bwd_ws_floats(int B, int H, int ndir);
 int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side input decoding (no GPU work, thread-safe, re-entrant): what tensorflow-io does for
+ * data.py:94-117 and what TFRecord framing needs (data.py:75, run/make_tfrecord.py:47).
+ * ------------------------------------------------------------------------------------------ */
+typedef enum asr_audio_format { ASR_AUDIO_WAV = 0, ASR_AUDIO_FLAC = 1, ASR_AUDIO_PCM16 = 2 } asr_audio_format;
+typedef struct asr_audio_info_t {
+  int sample_rate;       /* 0 for headerless PCM                              */
+  int channels;
+  int bits_per_sample;
+  long frames;           /* samples per channel                               */
+} asr_audio_info_t;
+/* file: the whole audio file in host memory */
+int asr_audio_info(const uint8_t* file, long nbytes, int format, asr_audio_info_t* info);
+/* Decodes to mono float32 as data.py:97-117 does: int16 / 32768 per channel, then the mean over
+ * channels.  out: host buffer of `capacity` floats (>= info.frames); *n_out = samples written.
+ * 16-bit sources only (the reference opens files as tf.int16); FLAC: every subframe type, both Rice
+ * codings, all stereo decorrelation modes, header CRC-8 and frame CRC-16 verified. */
+int asr_audio_decode(const uint8_t* file, long nbytes, int format, float* out, long capacity, long* n_out);
+/* CRC-32C (Castagnoli) of n bytes continuing from `crc` (0 to start) */
+uint32_t asr_crc32c(const void* data, long n, uint32_t crc);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,13 @@ class LrSchedule(C.Structure):
                 ("min_learning_rate", C.c_float), ("warmup_steps", C.c_int), ("offset_steps", C.c_int)]
 
 
-STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom,
+class AudioInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("bits_per_sample", C.c_int), ("frames", c_long)]
+
+
+AUDIO_FORMATS = {"wav": 0, "flac": 1, "pcm": 2}
+
+STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom, "asr_audio_info_t": AudioInfo,
            "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_back_src": RnnBackSrc, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
            "asr_rnn_seq_grad": RnnSeqGrad, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
            "asr_lr_schedule": LrSchedule}
@@ -108,6 +114,8 @@ SIGNATURES = {
     "asr_logmel_table_sizes": (C.c_int, [C.POINTER(LogmelCfg), C.POINTER(c_long), C.POINTER(c_long), C.POINTER(c_long)]),
     "asr_logmel_build_tables": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, _P]),
     "asr_logmel_features": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "asr_spec_augment": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "asr_delta_accelerate": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "asr_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
@@ -153,6 +161,9 @@ SIGNATURES = {
     "asr_ctc_loss": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int,
                                C.c_float, _P]),
     "asr_mask_rows": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, _P, c_long, _P]),
+    "asr_audio_info": (C.c_int, [C.c_char_p, c_long, C.c_int, C.POINTER(AudioInfo)]),
+    "asr_audio_decode": (C.c_int, [C.c_char_p, c_long, C.c_int, _P, c_long, C.POINTER(c_long)]),
+    "asr_crc32c": (C.c_uint32, [C.c_char_p, c_long, C.c_uint32]),
 }
 
 _lib = None

@@ -31,6 +31,7 @@ extern "C" long asr_struct_size(const char* name) {
   SZ(asr_conv_desc);
   SZ(asr_rowdrop);
   SZ(asr_lr_schedule);
+  SZ(asr_audio_info_t);
 #undef SZ
   return -1;
 }

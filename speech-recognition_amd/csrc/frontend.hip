@@ -2,8 +2,8 @@
 // + log + SpecAugment masks + delta / delta-delta + zero padding, one pass over the audio.
 // Replaces data.py:169-187, 282-301, 319-324 and the padded_batch of run/train.py:189-197.
 //
-// One workgroup = one clip x 64 consecutive frames (62 written + 2 halo frames for the two causal
-// differences).  HBM traffic is the algorithmic minimum: every sample is read once per tile
+// One workgroup = one clip x 16*MT consecutive frames (MT = 4 unless the frame parameters need more LDS
+// than a CU has; all but 2 are written, 2 are halo frames for the two causal differences).  HBM traffic is the algorithmic minimum: every sample is read once per tile
 // (+2 halo frames) and every output element written once; the twiddle table (window folded in,
 // stored in MFMA fragment order) and the mel matrix stay L2 resident.
 #include <math.h>
@@ -12,7 +12,7 @@
 
 #include "common.h"
 
-#define FE_FR 64  // frames per workgroup (incl. 2 halo)
+#define FE_FR_MAX 64  // frames per workgroup (incl. 2 halo) at MT = 4
 #define FE_MAXBAND 16
 
 struct FeArgs {
@@ -31,7 +31,9 @@ struct FeArgs {
   float sa_p;
 };
 
+template <int MT>
 __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
+  constexpr int FE_FR = 16 * MT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* seg = smem;                         // padded sample segment
   float* P = seg + a.seg_floats;             // [FE_FR][PLD] power spectrum
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
   // b. windowed DFT on the MFMA: [64 frames x L] x [L x (cos|sin) 16 bins], power -> P
   const int li = lane & 15, lq = lane >> 4;
   for (int bt = wave; bt < a.NBT; bt += 4) {
-    f32x4 ac[4], as[4];
+    f32x4 ac[MT], as[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { ac[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; as[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int m = 0; m < MT; ++m) { ac[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; as[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const float* twc = a.tw + (long)(bt * 2 + 0) * a.KS * 64 + lane;
     const float* tws = a.tw + (long)(bt * 2 + 1) * a.KS * 64 + lane;
     for (int ks = 0; ks < a.KS; ++ks) {
@@ -95,14 +97,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
       const int k = 4 * ks + lq;
       const int koff = k + a.pad * (k / a.step);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const float av = seg[(m * 16 + li) * fstride + koff];
         ac[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bc, ac[m], 0, 0, 0);
         as[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bs, as[m], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int frame = m * 16 + lq * 4 + r;
@@ -153,9 +155,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ host
-static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a) {
-  ASR_CHECK(c->frame_length > 0 && c->frame_step > 0 && c->fft_length >= c->frame_length && c->num_mel_bins > 0,
-            ASR_ERR_SHAPE, "logmel: need frame_length>0, frame_step>0, fft_length>=frame_length, num_mel_bins>0");
+static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a, int FE_FR = FE_FR_MAX) {
+  ASR_CHECK(c->frame_length > 0 && c->frame_step > 0 && c->fft_length > 0 && c->num_mel_bins > 0,
+            ASR_ERR_SHAPE, "logmel: need frame_length>0, frame_step>0, fft_length>0, num_mel_bins>0");
   ASR_CHECK(c->sa_mF <= FE_MAXBAND && c->sa_mT <= FE_MAXBAND, ASR_ERR_SHAPE, "logmel: m_F/m_T > %d", FE_MAXBAND);
   a->L = c->frame_length; a->step = c->frame_step; a->bins = c->fft_length / 2 + 1; a->nmel = c->num_mel_bins;
   a->C = c->use_delta ? 3 : 1;
@@ -170,7 +172,7 @@ static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a) {
   a->sa_mT = c->sa_enable ? c->sa_mT : 0; a->sa_p = c->sa_p;
   return ASR_OK;
 }
-static size_t fe_smem_bytes(const FeArgs& a) {
+static size_t fe_smem_bytes(const FeArgs& a, int FE_FR) {
   return sizeof(float) * ((size_t)a.seg_floats + (size_t)FE_FR * a.PLD + (size_t)FE_FR * a.nmel) + sizeof(int) * 4 * FE_MAXBAND;
 }
 
@@ -198,7 +200,8 @@ extern "C" int asr_logmel_build_tables(const asr_logmel_cfg* cfg, float* tw, flo
         for (int lane = 0; lane < 64; ++lane) {
           const int k = 4 * ks + (lane >> 4), bin = bt * 16 + (lane & 15);
           double v = 0.0;
-          if (k < a.L && bin < a.bins) {
+          // [TF-sem] tf.signal.stft: rfft crops the windowed frame to fft_length samples when it is shorter
+          if (k < a.L && k < cfg->fft_length && bin < a.bins) {
             const double w = 0.5 - 0.5 * cos(2.0 * PI * k / a.L);
             const long kb = ((long)k * bin) % cfg->fft_length;
             const double ang = 2.0 * PI * (double)kb / cfg->fft_length;
@@ -242,19 +245,28 @@ extern "C" int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio
   ASR_CHECK(B > 0 && n_max > 0 && T_out > 0, ASR_ERR_SHAPE, "asr_logmel_features: B, n_max, T_out must be > 0");
   ASR_CHECK(!(cfg->sa_enable && !seed), ASR_ERR_ARG, "asr_logmel_features: SpecAugment needs a device seed");
   FeArgs a{};
-  int rc = fe_geometry(cfg, &a);
-  if (rc) return rc;
+  int MT = 4, rc = 0;
+  size_t smem = 0;
+  for (; MT >= 1; MT >>= 1) {            // fewer frames per workgroup when long frames would not fit in LDS
+    rc = fe_geometry(cfg, &a, 16 * MT);
+    if (rc) return rc;
+    smem = fe_smem_bytes(a, 16 * MT);
+    if (smem <= 160 * 1024) break;
+  }
+  ASR_CHECK(MT >= 1, ASR_ERR_SHAPE, "asr_logmel_features: frame parameters need %zu B of LDS (> 160 KiB)", smem);
   a.audio = audio; a.n_samples = n_samples; a.tw = tw; a.melw = melw; a.melrange = melrange; a.seed = seed; a.out = out;
   a.B = B; a.n_max = n_max; a.T_out = T_out;
-  const size_t smem = fe_smem_bytes(a);
-  ASR_CHECK(smem <= 160 * 1024, ASR_ERR_SHAPE, "asr_logmel_features: frame parameters need %zu B of LDS (> 160 KiB)", smem);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid((unsigned)asr_cdiv(T_out, FE_FR - 2), (unsigned)B);
-  hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), smem, (hipStream_t)stream, a);
+  dim3 grid((unsigned)asr_cdiv(T_out, 16 * MT - 2), (unsigned)B);
+  if (MT == 4) hipLaunchKernelGGL(logmel_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  else if (MT == 2) hipLaunchKernelGGL(logmel_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(logmel_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

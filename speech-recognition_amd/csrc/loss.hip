@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(float* logits, long l
   const float lse = mx + logf(s);
   const float inv_cnt = cnt > 0.f ? 1.f / cnt : 0.f;
   if (tid == 0) {
-    const float xy = IN_LDS ? row[y] : x[y];
+    // a label outside [0, V) never indexes memory: NaN loss, as TF's GPU kernel reports it
+    const float xy = (y >= 0 && y < V) ? (IN_LDS ? row[y] : x[y]) : NAN;
     atomicAdd(&stats[0], (lse - xy) * inv_cnt);
     atomicAdd(&stats[1], am == y ? 1.f : 0.f);
     if (r == 0) stats[2] = cnt;

@@ -92,6 +92,80 @@ class LogmelPlan:
         return out
 
 
+class StoredFeaturePlan:
+    """Front end for batches that arrive as stored log-mel frames [B, T, v, 1] (run/train.py:70-74
+    --use-tfrecord): SpecAugment (training) and delta/delta-delta on the device.  Same call interface as
+    LogmelPlan, with `audio` = the stored features and `n_samples` = frames per clip."""
+
+    def __init__(self, num_mel_bins, use_delta=True, spec_augment=None):
+        sa = spec_augment or {}
+        if sa.get("W"):
+            raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
+        enable = bool(spec_augment) and bool(sa.get("enable", True))
+        self.cfg = spec_augment_cfg(num_mel_bins, sa.get("F"), sa.get("m_F"), sa.get("T"), sa.get("p"), sa.get("m_T")) if enable \
+            else spec_augment_cfg(num_mel_bins)
+        self.num_mel_bins, self.use_delta = num_mel_bins, use_delta
+        self.channels = 3 if use_delta else 1
+        self._scratch = {}
+
+    def num_frames(self, n_frames: int) -> int:
+        return n_frames
+
+    def __call__(self, feats, n_frames, T_out, seed=None, out=None):
+        _dev(feats, name="feats")
+        B, T = feats.shape[:2]
+        assert T_out == T and feats.is_contiguous()
+        if out is None:
+            out = torch.empty(B, T, self.num_mel_bins, self.channels, device=feats.device, dtype=torch.float32)
+        src = feats
+        if self.cfg.sa_enable:
+            if seed is None:
+                raise ValueError("StoredFeaturePlan: SpecAugment needs a device seed")
+            if self.use_delta:
+                key = tuple(feats.shape)
+                if key not in self._scratch:
+                    self._scratch[key] = torch.empty_like(feats)
+                src = self._scratch[key]
+            else:
+                src = out.view(feats.shape)
+            src.copy_(feats)
+            spec_augment_(self.cfg, src.view(B, T, self.num_mel_bins, 1), n_frames, seed)
+        if self.use_delta:
+            delta_accelerate(src, n_frames, out)
+        elif src is feats:
+            out.view(feats.shape).copy_(feats)
+        return out
+
+
+def spec_augment_cfg(v, F=None, m_F=None, T=None, p=None, m_T=None):
+    """asr_logmel_cfg carrying only the SpecAugment fields (for asr_spec_augment on stored features)."""
+    use_f, use_t = all([F, m_F]), all([T, p, m_T])
+    return _lib.LogmelCfg(0, 0, 0, 0, int(v), 0.0, 0.0, 0.0, 0, 1 if (use_f or use_t) else 0, int(F) if use_f else 0,
+                          int(m_F) if use_f else 0, int(T) if use_t else 0, int(m_T) if use_t else 0, float(p) if use_t else 0.0)
+
+
+def spec_augment_(cfg, x, n_frames, seed):
+    """In-place SpecAugment of x [B, T, v, C]; n_frames i32 [B] or None; seed: device i32/u32 [>=1]."""
+    _dev(x, name="x")
+    _dev(n_frames, torch.int32, "n_frames")
+    _dev(seed, torch.int32, "seed")
+    assert x.dim() == 4 and x.is_contiguous() and x.shape[2] == cfg.num_mel_bins
+    check(lib().asr_spec_augment(C.byref(cfg), _p(x), _p(n_frames), x.shape[0], x.shape[1], x.shape[3], _p(seed), _stream()))
+    return x
+
+
+def delta_accelerate(x, n_frames=None, out=None):
+    """x [B, T, v] (or [B, T, v, 1]) -> [B, T, v, 3] = (x, delta, delta-delta)."""
+    _dev(x, name="x")
+    _dev(n_frames, torch.int32, "n_frames")
+    assert x.is_contiguous() and (x.dim() == 3 or (x.dim() == 4 and x.shape[3] == 1))
+    B, T, v = x.shape[:3]
+    if out is None:
+        out = torch.empty(B, T, v, 3, device=x.device, dtype=torch.float32)
+    check(lib().asr_delta_accelerate(_p(x), _p(n_frames), B, T, v, _p(out), _stream()))
+    return out
+
+
 # ----------------------------------------------------------------------------------------- GEMM
 def _mat(t, name):
     _dev(t, name=name)

@@ -60,10 +60,13 @@ class GradientExchange:
 
 class TrainStep:
     def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
-                 beta1=0.9, beta2=0.999, eps=1e-7):
+                 beta1=0.9, beta2=0.999, eps=1e-7, eval_frontend=None):
         """model: LAS or DeepSpeech2 (built lazily on the first batch); lr_schedule: utils.LRScheduler;
-        frontend: LogmelPlan when batches arrive as raw audio, None when they are feature tensors."""
+        frontend: LogmelPlan when batches arrive as raw audio, StoredFeaturePlan when they are stored
+        log-mel frames, None when they are finished feature tensors; eval_frontend: the same without
+        SpecAugment, used by evaluate()."""
         self.model, self.frontend, self.strategy = model, frontend, strategy
+        self.eval_frontend = eval_frontend
         self.sched_host = lr_schedule
         self.sched = lr_schedule.device_schedule()
         self.use_graph = use_graph
@@ -163,6 +166,30 @@ class TrainStep:
         m.weights_changed()
         self.iterations += 1
         return c["ws"]
+
+    def evaluate(self, audio, n_samples, tokens, use_teacher_forcing: Optional[bool] = None):
+        """Validation pass of model.fit (run/train.py:203): forward(training=False) + loss + metric on one
+        batch, no SpecAugment, no update.  The teacher-forcing coin is drawn as in training (las.py:366 has
+        no training guard).  Returns the host list [loss, #correct, #kept]."""
+        m = self.model
+        c = self._ctx(audio, n_samples, tokens)
+        if use_teacher_forcing is None:
+            use_teacher_forcing = m.draw_teacher_forcing()
+        fe = self.eval_frontend if self.eval_frontend is not None else self.frontend
+        with torch.cuda.stream(self.stream):
+            c["audio"].copy_(audio, non_blocking=True)
+            if c["n_samples"] is not None:
+                c["n_samples"].copy_(n_samples, non_blocking=True)
+            c["tokens"].copy_(tokens, non_blocking=True)
+            m.set_targets(c["ws"], c["tokens"], c["labels"])
+            if fe is not None:
+                if fe.cfg.sa_enable:
+                    raise ValueError("evaluate: the evaluation front end must not apply SpecAugment")
+                fe(c["audio"], c["n_samples"], c["feats"].shape[1], out=c["feats"])
+            m.pack_weights()
+            m.forward_ws(c["ws"], c["feats"], False, bool(use_teacher_forcing))
+            m.loss_and_grad(c["ws"], c["labels"], 1.0)
+        return self.read_stats(c["ws"])
 
     def synchronize(self):
         self.stream.synchronize()
