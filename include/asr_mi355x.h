@@ -336,6 +336,23 @@ int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Greedy decoding (search.py).  All state stays on the device: a decode needs no host round trip per step.
+ * asr_greedy_update - one step of LAS_Searcher.greedy_search (search.py:41-55) on logits [B, V]:
+ *   (lp, tok) = top-1 of log_softmax (ties -> lowest index); log_ppl += lp unless ended; tok = pad if ended;
+ *   ended |= tok == eos; seq_len = cur_len + 1 where tok == eos; next_tok = tok.  cur_len = tokens decoded so
+ *   far including BOS (tf.shape(decoder_input)[1]).
+ * asr_ctc_greedy - DeepSpeechSearcher.greedy_search (search.py:223-252) on logits [B*T, V]: the blank competes
+ *   as the LAST class (ties go to non-blank), log-probabilities are log_softmax over the V classes, repeats are
+ *   merged and blanks dropped ([TF-sem] tf.nn.ctc_greedy_decoder): tokens [B, T] zero padded, lengths [B],
+ *   neg_sum_logits [B] = -sum_t max log-prob.  best [B*T] int32 / best_lp [B*T] f32 are scratch that also
+ *   hold the per-frame alignment (class V = blank) and its log-probability on return.
+ * ------------------------------------------------------------------------------------------ */
+int asr_greedy_update(const float* logits, long ld, int B, int V, int cur_len, int eos, int pad, int32_t* next_tok,
+                      uint8_t* ended, float* log_ppl, int32_t* seq_len, void* stream);
+int asr_ctc_greedy(const float* logits, long ld, int B, int T, int V, int blank, int32_t* best, float* best_lp,
+                   int32_t* tokens, int32_t* lengths, float* neg_sum_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Host-side input decoding (no GPU work, thread-safe, re-entrant): what tensorflow-io does for
  * data.py:94-117 and what TFRecord framing needs (data.py:75, run/make_tfrecord.py:47).
  * ------------------------------------------------------------------------------------------ */

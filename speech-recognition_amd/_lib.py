@@ -161,6 +161,8 @@ SIGNATURES = {
     "asr_ctc_loss": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int,
                                C.c_float, _P]),
     "asr_mask_rows": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, _P, c_long, _P]),
+    "asr_greedy_update": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "asr_ctc_greedy": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "asr_audio_info": (C.c_int, [C.c_char_p, c_long, C.c_int, C.POINTER(AudioInfo)]),
     "asr_audio_decode": (C.c_int, [C.c_char_p, c_long, C.c_int, _P, c_long, C.POINTER(c_long)]),
     "asr_crc32c": (C.c_uint32, [C.c_char_p, c_long, C.c_uint32]),

@@ -75,10 +75,32 @@ class ModelProto(metaclass=ABCMeta):
         self.weights_changed()
 
     def save_weights(self, path):
-        torch.save(self.state_dict(), path)
+        """Keras `save_weights(path)` (run/train.py:208-212): a TensorFlow tensor-bundle checkpoint
+        (<path>.index + <path>.data-00000-of-00001) with the reference's variable paths, so the files are
+        interchangeable with the reference's.  A path ending in '.pt' writes a torch state dict instead."""
+        if path.endswith(".pt"):
+            torch.save(self.state_dict(), path)
+            return
+        from ..checkpoint import save_variables
+        save_variables(path, {k: v.numpy() for k, v in self.state_dict().items()})
 
     def load_weights(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu"))
+        """Keras `load_weights(path)` (run/train.py:152-154): reads a tensor-bundle checkpoint written by the
+        reference or by save_weights; every model variable must be present with its exact shape."""
+        import os
+        if path.endswith(".pt") or (os.path.isfile(path) and not os.path.exists(path + ".index")):
+            self.load_state_dict(torch.load(path, map_location="cpu"))
+            return
+        from ..checkpoint import load_variables
+        values = load_variables(path)
+        mine = self.state_dict()
+        missing = sorted(set(mine) - set(values))
+        if missing:
+            raise ValueError(f"load_weights: {path} lacks {len(missing)} variables of {type(self).__name__}, e.g. {missing[:3]}")
+        for k, v in mine.items():
+            if tuple(values[k].shape) != tuple(v.shape):
+                raise ValueError(f"load_weights: {k} has shape {tuple(values[k].shape)} in {path}, the model needs {tuple(v.shape)}")
+        self.load_state_dict({k: torch.from_numpy(values[k]) for k in mine})
 
     def weights_changed(self):
         """Re-derive any packed weight image (call after every optimizer step / weight load)."""

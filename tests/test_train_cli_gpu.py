@@ -57,14 +57,16 @@ def test_train(tmp_path, model_config, use_tfrecord, policy, mixed):
     state = open(os.path.join(tmp_path, "models", "checkpoint")).read()
     ckpt = state.split('"')[1]
     assert ckpt.startswith("model-1epoch-") and ckpt.endswith(".ckpt")
-    assert os.path.exists(os.path.join(tmp_path, "models", ckpt))
+    assert os.path.exists(os.path.join(tmp_path, "models", ckpt + ".index"))       # TF tensor-bundle files
+    assert os.path.exists(os.path.join(tmp_path, "models", ckpt + ".data-00000-of-00001"))
 
 
 def test_checkpoint_reloads_bit_exactly(tmp_path):
     from speech_recognition_amd.configs import get_model_config
     _run(tmp_path, LAS_MINI, False, None)
     ckpt = open(os.path.join(tmp_path, "models", "checkpoint")).read().split('"')[1]
-    saved = torch.load(os.path.join(tmp_path, "models", ckpt), map_location="cpu")
+    from speech_recognition_amd.checkpoint import load_variables
+    saved = load_variables(os.path.join(tmp_path, "models", ckpt))
     model = get_model_config(LAS_MINI).create_model()
     model.build(80, 3)
     model.load_weights(os.path.join(tmp_path, "models", ckpt))
