@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Headline benchmark: audio-seconds/second of LAS training (BASELINE.json metric) on MI355X.
+"""Headline benchmark: audio-seconds/second of training (BASELINE.json metric) on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1: plain python)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload las_small|deepspeech|las_large]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = SURVEY.md 8d config 2: las_small.yml + libri_config.yml, synthetic 10 s / 16 kHz clips,
-batch 32 per GPU, 65-token rows (64 decoder steps), SpecAugment (F=27, m_F=2, T=100, p=1.0, m_T=2) and
-delta features computed ON the GPU inside the step, dropout 0.15 active, teacher forcing on,
-forward + backward + (RCCL gradient all-reduce) + Adam(lr 2e-4, LRScheduler).  fp32 throughout.
+Default workload = SURVEY.md 8d config 2 (the one BASELINE.json's metric is quoted on): las_small.yml +
+libri_config.yml, synthetic 10 s / 16 kHz clips, batch 32 per GPU, 65-token rows (64 decoder steps),
+SpecAugment (F=27, m_F=2, T=100, p=1.0, m_T=2) and delta features computed ON the GPU inside the step,
+dropout 0.15 active, teacher forcing on, forward + backward + (RCCL gradient all-reduce) + Adam(lr 2e-4,
+LRScheduler).  fp32 throughout.  --workload deepspeech / las_large run SURVEY.md 8d configs 4 / 5 the
+same way (las_large in fp32: this build has no bf16 path, the line says so).
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
 """
 import argparse
@@ -22,10 +24,25 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-CLIP_SECONDS, SAMPLE_RATE, BATCH, TOKENS = 10.0, 16000, 32, 65
-# SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step (3 x forward, key projection counted once)
-ALGO_FLOPS_PER_STEP = 363.3e9
+SAMPLE_RATE = 16000
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+# SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
+WORKLOADS = {
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9,
+                      metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
+                      text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
+                           "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
+    "deepspeech": dict(model="deepspeech.yml", clip_seconds=15.0, batch=16, tokens=96, flops=593.4e9,
+                       metric="audio-seconds/sec training (deepspeech, 15s clips, bs16)",
+                       text="deepspeech.yml + libri_config.yml, synthetic 15 s 16 kHz clips, batch 16 per GPU, 96 CTC labels, "
+                            "SpecAugment+delta on GPU, dropout 0.1, mask mode 'intended', fwd+CTC+bwd+Adam(lr 2e-4)"),
+    "las_large": dict(model="las_large.yml", clip_seconds=20.0, batch=64, tokens=128, flops=22.85e12,
+                      metric="audio-seconds/sec training (las_large, 20s clips, bs64)",
+                      text="las_large.yml + libri_config.yml, synthetic 20 s 16 kHz clips, batch 64 per GPU, 127 decoder steps, "
+                           "SpecAugment+delta on GPU, teacher forcing on, fwd+bwd+Adam(lr 2e-4); fp32 (north_star names bf16: not built)"),
+}
 
 
 def load_yaml(name):
@@ -34,44 +51,57 @@ def load_yaml(name):
         return yaml.safe_load(f)
 
 
-def synthetic_batch(rank, B=BATCH):
-    """N(0, 0.1^2) clipped to [-1,1], seed 1234(+rank); tokens [2, 63 x U{17..15999}, 3], seed 4321."""
+def synthetic_batch(rank, wl, B=None):
+    """audio N(0, 0.1^2) clipped to [-1,1], seed 1234(+rank); tokens [2, U{17..15999}..., 3], seed 4321
+    (DeepSpeech2 labels avoid the blank index 14 - they are >= 17 anyway)."""
+    B = B or wl["batch"]
     g = np.random.default_rng(1234 + rank)
-    audio = np.clip(g.standard_normal((B, int(CLIP_SECONDS * SAMPLE_RATE)), dtype=np.float32) * 0.1, -1.0, 1.0)
+    audio = np.clip(g.standard_normal((B, int(wl["clip_seconds"] * SAMPLE_RATE)), dtype=np.float32) * 0.1, -1.0, 1.0)
     g2 = np.random.default_rng(4321 + rank)
-    toks = g2.integers(17, 16000, size=(B, TOKENS), dtype=np.int32)
+    toks = g2.integers(17, 16000, size=(B, wl["tokens"]), dtype=np.int32)
     toks[:, 0], toks[:, -1] = 2, 3
     n = np.full((B,), audio.shape[1], np.int32)
     return audio, n, toks
 
 
-def build_trainer(strategy=None, use_graph=True):
+def build_trainer(wl, strategy=None, use_graph=True):
     from speech_recognition_amd import ops
-    from speech_recognition_amd.models import LAS
+    from speech_recognition_amd.configs import get_model_config
     from speech_recognition_amd.training import TrainStep
     from speech_recognition_amd.utils import LRScheduler
-    mc, dc = load_yaml("las_small.yml"), load_yaml("libri_config.yml")
+    dc = load_yaml("libri_config.yml")
     sa = dict(dc["spec_augment"], enable=True)     # 8d: SpecAugment on with the shipped parameters
     plan = ops.LogmelPlan(dc["sample_rate"], dc["frame_length"], dc["frame_step"], dc["fft_length"], dc["num_mel_bins"],
                           dc["lower_edge_hertz"], dc["upper_edge_hertz"], use_delta=dc["use_delta_accelerate"], spec_augment=sa)
-    model = LAS(mc["rnn_type"], mc["vocab_size"], mc["encoder_hidden_dim"], mc["decoder_hidden_dim"], mc["num_encoder_layers"],
-                mc["num_decoder_layers"], mc["dropout"], mc["teacher_forcing_rate"], mc["pad_id"], seed=1234)
+    model = get_model_config(os.path.join(ROOT, "resources", "configs", wl["model"])).create_model(seed=1234)
     sched = LRScheduler(total_steps=100000, max_learning_rate=2e-4, min_learning_rate=1e-5)
     return TrainStep(model, sched, frontend=plan, strategy=strategy, use_graph=use_graph), model
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may run on, capped at the GPU box's share (16 per
+    GPU) - os.cpu_count() reports the whole host and oversubscribing it stalls the intra-op thread pool."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(budget_s=25.0):
     """The oracle (oracle/: CPU restatement of the reference, torch-CPU fp32) timed on a bounded sample
-    of the same workload: ONE las_small training step (features -> forward -> loss -> backward -> Adam)
+    of the headline workload: ONE las_small training step (features -> forward -> loss -> backward -> Adam)
     on a reduced batch.  Reported baseline only (kind "port": TensorFlow, the reference's engine, is not
     installed and cannot be)."""
     from oracle import features as OF
     from oracle import las as OLAS
     from oracle import measure as OM
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    wl = WORKLOADS["las_small"]
     mc, dc = load_yaml("las_small.yml"), load_yaml("libri_config.yml")
     B = 4
-    audio, n, toks = synthetic_batch(0, B)
+    audio, n, toks = synthetic_batch(0, wl, B)
     g = torch.Generator().manual_seed(0)
     shapes = OLAS.param_shapes(mc)
     params = {}
@@ -95,8 +125,58 @@ def cpu_baseline(budget_s=25.0):
     with torch.no_grad():
         OM.adam_step({k: v for k, v in train.items()}, {k: v.grad for k, v in train.items()}, m, vv, 0, 2e-4)
     dt = time.perf_counter() - t0
-    return {"value": round(B * CLIP_SECONDS / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(B * wl["clip_seconds"] / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
             "sample": f"1 las_small training step (front end+fwd+bwd+Adam), batch {B} x 10 s clips, torch-CPU fp32 oracle, {dt:.1f} s"}
+
+
+def time_kernel(stream, fn, iters=20):
+    """Average duration (s) of fn() launched back to back on `stream`, by HIP events on that stream."""
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_rooflines(trainer, model, audio_d, n_d):
+    """Per-kernel rooflines of the las_small step's three heaviest non-recurrent kernels, each timed alone on the
+    trainer's stream: the encoder input-projection GEMM (MFMA bound), the vocabulary GEMM (MFMA bound) and the
+    fused front end (HBM bound, algorithmic bytes = SURVEY.md 8d: 160 KB per audio-second)."""
+    from speech_recognition_amd import ops
+    out = []
+    B, He, Hd, V = audio_d.shape[0], model.He, model.Hd, model.V
+    c = next(iter(trainer._shapes.values()))
+    ws = c["ws"]
+    M = B * ws.T2
+    a = torch.randn(M, 2 * He, device="cuda")
+    w = torch.randn(2 * He, 8 * He, device="cuda") * 0.05     # both directions' [Din, 4H] kernels side by side
+    y = torch.empty(M, 8 * He, device="cuda")
+    t = time_kernel(trainer.stream, lambda: ops.gemm(a, w, y))
+    fl = 2.0 * M * 2 * He * 8 * He
+    out.append({"kernel": f"gemm_f32 encoder input projection [{M}x{2 * He}]x[{2 * He}x{8 * He}]", "bound": "mfma",
+                "achieved": round(fl / t / 1e12, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / t / PEAK_F32_MFMA, 4),
+                "us": round(t * 1e6, 1)})
+    U = ws.U
+    yd = torch.randn(U * B, Hd, device="cuda")
+    wv = torch.randn(Hd, V, device="cuda") * 0.05
+    lg = torch.empty(U * B, V, device="cuda")
+    t = time_kernel(trainer.stream, lambda: ops.gemm(yd, wv, lg))
+    fl = 2.0 * U * B * Hd * V
+    out.append({"kernel": f"gemm_f32 vocabulary projection [{U * B}x{Hd}]x[{Hd}x{V}]", "bound": "mfma",
+                "achieved": round(fl / t / 1e12, 2), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": round(fl / t / PEAK_F32_MFMA, 4),
+                "us": round(t * 1e6, 1)})
+    fe = trainer.frontend
+    feats = c["feats"]
+    t = time_kernel(trainer.stream, lambda: fe(audio_d, n_d, feats.shape[1], seed=model.seed, out=feats))
+    byts = audio_d.numel() * 4 + feats.numel() * 4
+    out.append({"kernel": "logmel_kernel (log-mel + SpecAugment + delta, fused)", "bound": "hbm", "achieved": round(byts / t / 1e9, 1),
+                "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(byts / t / PEAK_HBM, 4), "us": round(t * 1e6, 1)})
+    return out
 
 
 def main():
@@ -104,9 +184,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="las_small")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +196,22 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    # The CPU baseline runs first, before this process touches the GPU, under an alarm: it is a reported
+    # side number and must never hold up or take down the measured line.
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        import signal
+
+        def _too_slow(signum, frame):
+            raise TimeoutError("CPU baseline exceeded 150 s")
+        signal.signal(signal.SIGALRM, _too_slow)
+        signal.alarm(150)
+        try:
+            cpu = cpu_baseline()
+        except BaseException as e:
+            cpu = {"value": None, "unit": "audio-s/s", "cores": host_threads(), "kind": "port", "sample": f"failed: {e}"}
+        finally:
+            signal.alarm(0)
     torch.cuda.set_device(local)
     strategy = None
     if world > 1:
@@ -123,8 +221,8 @@ def main():
         from speech_recognition_amd.utils import DeviceStrategy
         strategy = DeviceStrategy(torch.device("cuda", local), world, rank)
 
-    trainer, model = build_trainer(strategy, use_graph=not args.no_graph)
-    audio, n, toks = synthetic_batch(rank)
+    trainer, model = build_trainer(wl, strategy, use_graph=not args.no_graph)
+    audio, n, toks = synthetic_batch(rank, wl)
     audio_d, n_d, toks_d = torch.from_numpy(audio).cuda(), torch.from_numpy(n).cuda(), torch.from_numpy(toks).cuda()
 
     def barrier():
@@ -153,26 +251,26 @@ def main():
     if rank != 0:
         return
     ms = dt / args.steps * 1e3
-    value = world * BATCH * CLIP_SECONDS * args.steps / dt
+    value = world * wl["batch"] * wl["clip_seconds"] * args.steps / dt
     dev_ms = ev0.elapsed_time(ev1) / args.steps
-    achieved = ALGO_FLOPS_PER_STEP / (dev_ms * 1e-3)
+    achieved = wl["flops"] / (dev_ms * 1e-3)
     out = {
-        "metric": "audio-seconds/sec training (las_small, 10s clips, bs32)", "value": round(value, 1), "unit": "audio-s/s",
+        "metric": wl["metric"], "value": round(value, 1), "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
-                               "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)",
-                   "global_batch": BATCH * world, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}",
-                   "hip_graph": not args.no_graph, "final_loss": round(loss, 4)},
+        "config": {"workload": wl["text"], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
+                   "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "final_loss": round(loss, 4)},
         "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
-                     "kernel": "whole training step (algorithmic 363.3 GFLOP/step, SURVEY.md 8d) over HIP-event step time"},
+                     "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"},
     }
-    if not args.no_cpu_baseline and world == 1:
+    if args.workload == "las_small" and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline()
-        except Exception as e:  # the baseline must never take the measured line down
-            out["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+            out["roofline"]["kernels"] = kernel_rooflines(trainer, model, audio_d, n_d)
+        except Exception as e:  # per-kernel extras must never take the measured line down
+            out["roofline"]["kernels"] = f"failed: {e}"
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     print(json.dumps(out))
 
 
