@@ -30,6 +30,21 @@ void asr_set_error(const char* fmt, ...);
 
 static inline int asr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Zero `bytes` (a multiple of 4) of device memory with an ordinary kernel on `st`.  Used instead of
+// hipMemsetAsync wherever the call may be captured into a hipGraph: memset nodes were observed to run out
+// of order with the kernel nodes that follow them when another process shares the GPU (stale accumulators
+// surviving into the next replay), kernel nodes of one stream never are.
+static __global__ void asr_zero_kernel(uint32_t* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t asr_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(asr_zero_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- stateless RNG (spec: oracle/rng.py)
 __host__ __device__ __forceinline__ uint32_t asr_fmix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;

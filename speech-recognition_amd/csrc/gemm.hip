@@ -1,4 +1,6 @@
 // asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h).
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an
@@ -68,6 +70,11 @@ static void launch_t(const GemmPlan& g, const AL& al, const BL& bl) {
     const double useful = (double)d->M * d->N * z;         // useful output elements
     return tile_eff * useful / ((double)rounds * 256 * bm * bn);
   };
+  static const int forced = getenv("ASR_GEMM_TILE") ? atoi(getenv("ASR_GEMM_TILE")) : 0;   // tuning aid: 1..4
+  if (forced == 1) { launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl); return; }
+  if (forced == 2) { launch_cfg<AL, BL, TA, TB, 128, 64, 2, 2>(g, al, bl); return; }
+  if (forced == 3) { launch_cfg<AL, BL, TA, TB, 64, 128, 2, 2>(g, al, bl); return; }
+  if (forced == 4) { launch_cfg<AL, BL, TA, TB, 64, 64, 2, 2>(g, al, bl); return; }
   const double s128 = score(128, 128, 1.0), s12864 = score(128, 64, 0.92), s64128 = score(64, 128, 0.92), s64 = score(64, 64, 0.80);
   if (s128 >= s12864 && s128 >= s64128 && s128 >= s64) launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl);
   else if (s12864 >= s64128 && s12864 >= s64) launch_cfg<AL, BL, TA, TB, 128, 64, 2, 2>(g, al, bl);

@@ -129,7 +129,7 @@ extern "C" int asr_bn_fwd(const float* x, int M, int C, long ld, const float* ga
   dim3 grid((unsigned)asr_cdiv(C, 64), (unsigned)asr_cdiv(M, rpb));
   if (training) {
     ASR_CHECK(mean_out && rstd_out && stats_ws, ASR_ERR_ARG, "asr_bn_fwd: training needs mean/rstd/stats buffers");
-    if (hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { asr_set_error("asr_bn_fwd: memset failed"); return ASR_ERR_HIP; }
+    if (asr_zero_async(stats_ws, sizeof(double) * 2 * C, st) != hipSuccess) { asr_set_error("asr_bn_fwd: memset failed"); return ASR_ERR_HIP; }
     hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, st, x, M, C, ld, stats_ws, rpb);
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, st, x, M, C, ld, stats_ws, gamma, beta, eps, momentum, relu, y, ldy,
                        mean_out, rstd_out, moving_mean, moving_var);
@@ -193,7 +193,7 @@ extern "C" int asr_bn_bwd(const float* x, const float* y, const float* dy, int M
   hipStream_t st = (hipStream_t)stream;
   const int rpb = 128;
   dim3 grid((unsigned)asr_cdiv(C, 64), (unsigned)asr_cdiv(M, rpb));
-  if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { asr_set_error("asr_bn_bwd: memset failed"); return ASR_ERR_HIP; }
+  if (asr_zero_async(sums_ws, sizeof(double) * 2 * C, st) != hipSuccess) { asr_set_error("asr_bn_bwd: memset failed"); return ASR_ERR_HIP; }
   hipLaunchKernelGGL(bn_bwd_stats_kernel, grid, dim3(256), 0, st, x, y, dy, M, C, ld, ldy, lddy, mean, rstd, relu, sums_ws, rpb);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, x, y, dy, M, C, ld, ldy, lddy, mean, rstd, gamma, relu, sums_ws, dx, lddx,
                      dgamma, dbeta);

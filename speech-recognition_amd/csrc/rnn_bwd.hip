@@ -273,7 +273,7 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
     ASR_CHECK(s->saved[d] && s->U[d] && gs->direct[d] && gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd: null buffer (dir %d)", d);
     ASR_CHECK(!lstm || gs->dc[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: LSTM needs a dc buffer (dir %d)", d);
     ASR_CHECK(!s->mask || gs->dy_carry[d], ASR_ERR_ARG, "asr_rnn_seq_bwd: masked sequences need dy_carry (dir %d)", d);
-    if (hipMemsetAsync(gs->direct[d], 0, sizeof(float) * (size_t)B * H, st) != hipSuccess) { asr_set_error("asr_rnn_seq_bwd: memset failed"); return ASR_ERR_HIP; }
+    if (asr_zero_async(gs->direct[d], sizeof(float) * (size_t)B * H, st) != hipSuccess) { asr_set_error("asr_rnn_seq_bwd: memset failed"); return ASR_ERR_HIP; }
   }
   const long ld_s = (long)T * NS * H;
   for (int step = T - 1; step >= -1; --step) {   // step == -1: gradient wrt the initial h (linear mode)

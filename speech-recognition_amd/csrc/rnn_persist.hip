@@ -236,7 +236,7 @@ extern "C" int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* st
   a.mask = s->mask; a.y = s->y; a.y_ld = s->y_ld;
   a.xbuf = ws;
   a.err = reinterpret_cast<unsigned*>(ws + ws_floats - 32);
-  a.spin_limit = 1 << 20;
+  a.spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_seq_fwd_persist: null buffer (dir %d)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_seq_fwd_persist: recurrent dropout is not supported");
@@ -246,8 +246,8 @@ extern "C" int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* st
     p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
   }
-  // every tag and the error word are zeroed on every call (a memset node when captured)
-  if (hipMemsetAsync(ws, 0, sizeof(float) * ws_floats, st) != hipSuccess) { asr_set_error("asr_rnn_seq_fwd_persist: memset failed"); return ASR_ERR_HIP; }
+  // every tag and the error word are zeroed on every call (by a kernel: see asr_zero_async)
+  if (asr_zero_async(ws, sizeof(float) * ws_floats, st) != hipSuccess) { asr_set_error("asr_rnn_seq_fwd_persist: memset failed"); return ASR_ERR_HIP; }
   dim3 grid((unsigned)Q, (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
   if (s->rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_seq_fwd_persist_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
   else if (s->rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_seq_fwd_persist_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);

@@ -240,7 +240,7 @@ extern "C" int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_g
   a.xbuf = ws;
   a.counters = reinterpret_cast<unsigned*>(ws + groups * 2 * NU * 1024);
   a.err = a.counters + groups * 32;
-  a.spin_limit = 1 << 20;
+  a.spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd_persist: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_seq_bwd_persist: null buffer (dir %d)", d);
@@ -253,7 +253,7 @@ extern "C" int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_g
     p.dc = gs->dc[d]; p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
   }
-  if (hipMemsetAsync(a.counters, 0, sizeof(unsigned) * (groups * 32 + 32), st) != hipSuccess) { asr_set_error("asr_rnn_seq_bwd_persist: memset failed"); return ASR_ERR_HIP; }
+  if (asr_zero_async(a.counters, sizeof(unsigned) * (groups * 32 + 32), st) != hipSuccess) { asr_set_error("asr_rnn_seq_bwd_persist: memset failed"); return ASR_ERR_HIP; }
   dim3 grid((unsigned)NU, (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
   dim3 block(64 * PB_NW);
   if (s->rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_seq_bwd_persist_kernel<CELL_LSTM>, grid, block, 0, st, a);

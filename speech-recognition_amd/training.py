@@ -133,7 +133,9 @@ class TrainStep:
             return
         if gkey not in c["graphs"]:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
+            # thread_local: RCCL's watchdog thread polls events while this thread captures; only this
+            # thread's own calls are part of (and can invalidate) the capture
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 fn()
             c["graphs"][gkey] = g
         c["graphs"][gkey].replay()
