@@ -4,7 +4,8 @@
 //
 //   forward      Y[pos][o]   = sum_kc im2col[pos][kc] W[kc][o] + b[o]            (NN, A gathered)
 //   bwd filter   dW[kc][o]  += sum_pos im2col[pos][kc] dY[pos][o]                (TN, A gathered, split-K)
-//   bwd data     dX[ipos][c] = sum_{r,s,o} dY[b,(h-r)/sh,(w-s)/sw,o] W[r,s,c,o]   (NT, both gathered)
+//   bwd data     dX[ipos][c] = sum_{r,s,o} dY[b,(h-r)/sh,(w-s)/sw,o] W[r,s,c,o]   (NT, both gathered; one
+//                stride-1 correlation per (h % sh, w % sw) class, see DyClassLoader)
 // pos = (b, ho, wo); kc = (r, s, c) with c fastest - exactly the HWIO kernel's row index.
 #include "gemm_core.h"
 
@@ -13,96 +14,146 @@ struct ConvGeom {
 };
 
 // stored logical matrix im2col [R = B*Ho*Wo][Cc = kh*kw*C]
+template <int VEC>   // VEC: C % 4 == 0 and x 16-byte aligned - a float4 of columns stays inside one kernel row
 struct Im2colLoader {
   const float* x;
   ConvGeom g;
-  int R, Cc, vec_ok;
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
-    if (r >= R || c >= Cc) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
-    const int wo = r % g.Wo, t = r / g.Wo, ho = t % g.Ho, b = t / g.Ho;
-    const long base = (((long)b * g.H + (long)ho * g.sh) * g.W + (long)wo * g.sw) * g.C;
-    const int rowlen = g.kw * g.C;  // one kernel row (s, c) is contiguous in the input
-    if (vec_ok && c + 3 < Cc) {
-      const int kr = c / rowlen, rem = c - kr * rowlen;       // rem..rem+3 stay inside the row (C % 4 == 0)
-      const float4 t4 = *reinterpret_cast<const float4*>(x + base + (long)kr * g.W * g.C + rem);
-      v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int cc = c + i;
-        if (cc < Cc) {
-          const int kr = cc / rowlen, rem = cc - kr * rowlen;
-          v[i] = x[base + (long)kr * g.W * g.C + rem];
-        } else v[i] = 0.f;
-      }
-    }
+  int R, Cc;
+  AsrDiv dWo, dHo, dRow;            // divisors Wo, Ho and kw*C (one kernel row (s, c) is contiguous in the input)
+  struct Row { long base; int ok; };
+  struct Col { long off[VEC ? 1 : 4]; int n; };   // !VEC: one offset per element (a group of 4 may straddle kernel rows)
+  __device__ __forceinline__ Row row(int r) const {
+    uint32_t t, wo, b, ho;
+    dWo.divmod((uint32_t)min(r, R - 1), t, wo);
+    dHo.divmod(t, b, ho);
+    return Row{(((long)b * g.H + (long)ho * g.sh) * g.W + (long)wo * g.sw) * g.C, r < R};
   }
-};
-
-// bwd-data A operand: stored logical matrix G [R = B*H*W][Cc = kh*kw*O],
-// G[(b,h,w)][(r,s,o)] = dY[b, (h-r)/sh, (w-s)/sw, o] when the division is exact and in range, else 0
-struct DyGatherLoader {
-  const float* dy;
-  ConvGeom g;
-  int R, Cc, vec_ok;
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (r >= R || c >= Cc) return;
-    const int w = r % g.W, t = r / g.W, h = t % g.H, b = t / g.H;
-    if (vec_ok && c + 3 < Cc) {   // O % 4 == 0 and c % 4 == 0: the four o share (r, s) and are contiguous
-      const int o = c % g.O, rs = c / g.O, s = rs % g.kw, kr = rs / g.kw;
-      const int hh = h - kr, ww = w - s;
-      if (hh < 0 || ww < 0 || hh % g.sh != 0 || ww % g.sw != 0) return;
-      const int ho = hh / g.sh, wo = ww / g.sw;
-      if (ho >= g.Ho || wo >= g.Wo) return;
-      const float4 t4 = *reinterpret_cast<const float4*>(dy + (((long)b * g.Ho + ho) * g.Wo + wo) * g.O + o);
-      v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+  __device__ __forceinline__ Col col(int c) const {
+    Col cl;
+    cl.n = max(0, min(4, Cc - c));
+#pragma unroll
+    for (int i = 0; i < (VEC ? 1 : 4); ++i) {
+      uint32_t kr, rem;
+      dRow.divmod((uint32_t)max(0, min(c + i, VEC ? Cc - 4 : Cc - 1)), kr, rem);   // clamped: the load is always legal
+      cl.off[i] = (long)kr * g.W * g.C + rem;
+    }
+    return cl;
+  }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    if (VEC) {                      // Cc % 4 == 0 too (C % 4 == 0): a fetch is all in or all out
+      const float4 t4 = *reinterpret_cast<const float4*>(x + rw.base + cl.off[0]);
+      const bool ok = rw.ok && cl.n == 4;
+      v[0] = ok ? t4.x : 0.f; v[1] = ok ? t4.y : 0.f; v[2] = ok ? t4.z : 0.f; v[3] = ok ? t4.w : 0.f;
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cc = c + i;
-      if (cc >= Cc) continue;
-      const int o = cc % g.O, rs = cc / g.O, s = rs % g.kw, kr = rs / g.kw;
-      const int hh = h - kr, ww = w - s;
-      if (hh < 0 || ww < 0 || hh % g.sh != 0 || ww % g.sw != 0) continue;
-      const int ho = hh / g.sh, wo = ww / g.sw;
-      if (ho >= g.Ho || wo >= g.Wo) continue;
-      v[i] = dy[(((long)b * g.Ho + ho) * g.Wo + wo) * g.O + o];
+    for (int i = 0; i < 4; ++i) v[i] = (rw.ok && i < cl.n) ? x[rw.base + cl.off[i]] : 0.f;
+  }
+};
+
+// bwd-data by stride class.  Input positions with h % sh == ph and w % sw == pw receive only the filter
+// taps r = ph + sh*i, s = pw + sw*j, and for all of them the same ones: with h = hq*sh + ph, w = wq*sw + pw
+//   dX[b, h, w, c] = sum_{i, j, o} dY[b, hq - i, wq - j, o] * W[ph + sh*i, pw + sw*j, c, o]
+// i.e. one stride-1 correlation per class over the sub-sampled filter - no multiplications by the zeros a
+// strided gather would insert (sh*sw times fewer MFMAs than the dense form).
+// Rows are ordered (b, wq, hq) and columns (j, i, o): a tile of consecutive rows then covers one or two
+// values of wq, for which only the taps j in [wq - (Wo-1), wq] can hit dY at all, and those taps are one
+// contiguous K range - the kernel restricts its K loop to it (the frequency axis is short against the
+// kernel width in DeepSpeech2: 40 % of the taps fall off the edge).
+// A operand of class (ph, pw): G [R = B*Wq*Hq][Cc = nS*nR*O], G[(b,wq,hq)][(j,i,o)] = dY[b, hq-i, wq-j, o] or 0
+template <int VEC>    // VEC: O % 4 == 0 and 16-byte aligned dY / W (the four o of a fetch share their tap)
+struct DyClassLoader {
+  const float* dy;
+  ConvGeom g;
+  int Hq, Wq, nR;     // class grid and taps per kernel column
+  int R, Cc;
+  AsrDiv dHq, dWq, dO, dnR;
+  struct Row { long bbase; int hq, wq, ok; };
+  struct Col { int o[VEC ? 1 : 4], i[VEC ? 1 : 4], j[VEC ? 1 : 4]; int n; };
+  __device__ __forceinline__ Row row(int r) const {
+    uint32_t t, hq, b, wq;
+    dHq.divmod((uint32_t)min(r, R - 1), t, hq);
+    dWq.divmod(t, b, wq);
+    return Row{(long)b * g.Ho * g.Wo * g.O, (int)hq, (int)wq, r < R};
+  }
+  __device__ __forceinline__ Col col(int c) const {
+    Col cl;
+    cl.n = max(0, min(4, Cc - c));
+#pragma unroll
+    for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+      uint32_t ij, o, j, i;
+      dO.divmod((uint32_t)max(0, min(c + e, VEC ? Cc - 4 : Cc - 1)), ij, o);
+      dnR.divmod(ij, j, i);
+      cl.o[e] = (int)o; cl.i[e] = (int)i; cl.j[e] = (int)j;
+    }
+    return cl;
+  }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    if (VEC) {
+      const int ho = rw.hq - cl.i[0], wo = rw.wq - cl.j[0];
+      const bool ok = rw.ok && cl.n == 4 && ho >= 0 && wo >= 0 && ho < g.Ho && wo < g.Wo;
+      const int hc = min(max(ho, 0), g.Ho - 1), wc = min(max(wo, 0), g.Wo - 1);     // clamped: the load is always legal
+      const float4 t4 = *reinterpret_cast<const float4*>(dy + rw.bbase + ((long)hc * g.Wo + wc) * g.O + cl.o[0]);
+      v[0] = ok ? t4.x : 0.f; v[1] = ok ? t4.y : 0.f; v[2] = ok ? t4.z : 0.f; v[3] = ok ? t4.w : 0.f;
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ho = rw.hq - cl.i[e], wo = rw.wq - cl.j[e];
+      const bool ok = rw.ok && e < cl.n && ho >= 0 && wo >= 0 && ho < g.Ho && wo < g.Wo;
+      v[e] = ok ? dy[rw.bbase + ((long)ho * g.Wo + wo) * g.O + cl.o[e]] : 0.f;
     }
   }
 };
 
-// bwd-data B operand: stored logical matrix Wt [R = C][Cc = kh*kw*O], Wt[c][(r,s,o)] = W[r,s,c,o]
-struct WtLoader {
+// B operand of class (ph, pw): Wt [R = C][Cc = nS*nR*O], Wt[c][(j,i,o)] = W[ph + sh*i, pw + sw*j, c, o]
+template <int VEC>
+struct WtClassLoader {
   const float* w;
   ConvGeom g;
-  int R, Cc, vec_ok;
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
+  int ph, pw, nR;
+  int R, Cc;
+  AsrDiv dO, dnR;
+  struct Row { long off; int ok; };
+  struct Col { long off[VEC ? 1 : 4]; int n; };
+  __device__ __forceinline__ Row row(int r) const { return Row{(long)min(r, R - 1) * g.O, r < R}; }
+  __device__ __forceinline__ Col col(int c) const {
+    Col cl;
+    cl.n = max(0, min(4, Cc - c));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int cc = c + i;
-      if (r < R && cc < Cc) {
-        const int o = cc % g.O, rs = cc / g.O;
-        v[i] = w[((long)rs * g.C + r) * g.O + o];
-      } else v[i] = 0.f;
+    for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+      uint32_t ij, o, j, i;
+      dO.divmod((uint32_t)max(0, min(c + e, VEC ? Cc - 4 : Cc - 1)), ij, o);
+      dnR.divmod(ij, j, i);
+      cl.off[e] = ((long)(ph + g.sh * (int)i) * g.kw + (pw + g.sw * (int)j)) * g.C * g.O + o;
     }
+    return cl;
+  }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    if (VEC) {     // the four o are contiguous in the HWIO kernel
+      const float4 t4 = *reinterpret_cast<const float4*>(w + cl.off[0] + rw.off);
+      const bool ok = rw.ok && cl.n == 4;
+      v[0] = ok ? t4.x : 0.f; v[1] = ok ? t4.y : 0.f; v[2] = ok ? t4.z : 0.f; v[3] = ok ? t4.w : 0.f;
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (rw.ok && e < cl.n) ? w[cl.off[e] + rw.off] : 0.f;
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(Im2colLoader al, PlainLoader bl, GemmEpilogue ep, int K, int tiles_m) {
-  using T = GemmTile<0, 0, BM, BN, WAVES_M, WAVES_N>;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(Im2colLoader<VEC> al, PlainLoader bl, GemmEpilogue ep, int K, int tiles_m) {
+  using T = GemmTile<0, 0, BM, BN, WAVES_M, WAVES_N, BK>;
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
   T::run(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader al, PlainLoader bl, GemmEpilogue ep, int K,
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+__global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader<VEC> al, PlainLoader bl, GemmEpilogue ep, int K,
                                                               int tiles_m, int k_chunk) {
-  using T = GemmTile<1, 0, BM, BN, WAVES_M, WAVES_N>;
+  using T = GemmTile<1, 0, BM, BN, WAVES_M, WAVES_N, BK>;
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
   const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
@@ -111,13 +162,25 @@ __global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader al, P
   T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(DyGatherLoader al, WtLoader bl, GemmEpilogue ep, int K, int tiles_m) {
-  using T = GemmTile<0, 1, BM, BN, WAVES_M, WAVES_N>;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(DyClassLoader<VEC> al, WtClassLoader<VEC> bl, GemmEpilogue ep, int K, int tiles_m, int k_per_j) {
+  using T = GemmTile<0, 1, BM, BN, WAVES_M, WAVES_N, BK>;
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
-  T::run(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
+  int kbeg = 0, kend = K;
+  if (k_per_j > 0) {   // taps j outside [wq - (Wo-1), wq] read only zeros for every row of this tile: skip them
+    const int r0 = bm * BM, r1 = min(r0 + BM, al.R) - 1;
+    const int t0 = r0 / al.Hq, t1 = r1 / al.Hq;
+    if (t0 / al.Wq == t1 / al.Wq) {                 // the tile stays inside one clip: wq runs from t0 % Wq to t1 % Wq
+      const int j_lo = max(0, t0 % al.Wq - (al.g.Wo - 1)), j_hi = min(K / k_per_j - 1, t1 % al.Wq);
+      kbeg = j_lo * k_per_j;
+      kend = max(kbeg, (j_hi + 1) * k_per_j);
+      al.Cc = kend;      // the loaders zero-fill from kend on, so the last K tile may be partial
+      bl.Cc = kend;
+    }
+  }
+  T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 static int conv_geom(const asr_conv_desc* d, ConvGeom* g) {
@@ -149,17 +212,22 @@ extern "C" int asr_conv2d_fwd(const asr_conv_desc* d, const float* x, const floa
   int rc = conv_geom(d, &g);
   if (rc) return rc;
   const int M = g.B * g.Ho * g.Wo, N = g.O, K = g.kh * g.kw * g.C;
-  Im2colLoader al{x, g, M, K, (g.C % 4 == 0) && al16(x)};
   PlainLoader bl{w, (long)N, K, N, (N % 4 == 0) && al16(w), nullptr, 1};
   GemmEpilogue ep{y, (long)N, M, N, 1.f, bias, nullptr, 1, 0, 0, (drop_rate > 0.f ? drop_seed : nullptr), drop_stream, drop_rate};
   ASR_CHECK(!(drop_rate > 0.f && !drop_seed), ASR_ERR_ARG, "asr_conv2d_fwd: dropout needs a device seed");
   hipStream_t st = (hipStream_t)stream;
+  const bool vec = (g.C % 4 == 0) && al16(x);
+  const AsrDiv dWo = asr_make_div(g.Wo), dHo = asr_make_div(g.Ho), dRow = asr_make_div(g.kw * g.C);
+  Im2colLoader<1> av{x, g, M, K, dWo, dHo, dRow};
+  Im2colLoader<0> as{x, g, M, K, dWo, dHo, dRow};
   if (N <= 32) {
     const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
-    hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, al, bl, ep, K, tm);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
   } else {
     const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
-    hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, al, bl, ep, K, tm);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -172,21 +240,27 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   int rc = conv_geom(d, &g);
   if (rc) return rc;
   const int M = g.kh * g.kw * g.C, N = g.O, K = g.B * g.Ho * g.Wo;
-  Im2colLoader al{x, g, K, M, (g.C % 4 == 0) && al16(x)};
   PlainLoader bl{dy, (long)N, K, N, (N % 4 == 0) && al16(dy), nullptr, 1};
   GemmEpilogue ep{dw, (long)N, M, N, 1.f, nullptr, nullptr, 1, 2, 0, nullptr, 0u, 0.f};
   hipStream_t st = (hipStream_t)stream;
+  const bool vec = (g.C % 4 == 0) && al16(x);
+  const AsrDiv dWo = asr_make_div(g.Wo), dHo = asr_make_div(g.Ho), dRow = asr_make_div(g.kw * g.C);
+  Im2colLoader<1> av{x, g, K, M, dWo, dHo, dRow};
+  Im2colLoader<0> as{x, g, K, M, dWo, dHo, dRow};
   const bool narrow = N <= 32;
   const int tm = asr_cdiv(M, narrow ? 256 : 64), tn = asr_cdiv(N, narrow ? 32 : 64);
   int splits = 1024 / (tm * tn);
   if (splits < 1) splits = 1;
-  int k_chunk = asr_cdiv(asr_cdiv(K, splits), GEMM_BK) * GEMM_BK;
-  if (k_chunk < 4 * GEMM_BK) k_chunk = 4 * GEMM_BK;
+  const int bk = 32;                         // K partitions are whole K tiles of the kernel used
+  int k_chunk = asr_cdiv(asr_cdiv(K, splits), bk) * bk;
+  if (k_chunk < 4 * bk) k_chunk = 4 * bk;
   splits = asr_cdiv(K, k_chunk);
   ASR_CHECK(splits <= 65535, ASR_ERR_SHAPE, "asr_conv2d_bwd_filter: too many K partitions");
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)splits);
-  if (narrow) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1>), grid, dim3(256), 0, st, al, bl, ep, K, tm, k_chunk);
-  else hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, al, bl, ep, K, tm, k_chunk);
+  if (narrow && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (narrow) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -196,18 +270,33 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
   ConvGeom g;
   int rc = conv_geom(d, &g);
   if (rc) return rc;
-  const int M = g.B * g.H * g.W, N = g.C, K = g.kh * g.kw * g.O;
-  DyGatherLoader al{dy, g, M, K, (g.O % 4 == 0) && al16(dy)};
-  WtLoader bl{w, g, N, K, 0};
-  GemmEpilogue ep{dx, (long)N, M, N, 1.f, nullptr, nullptr, 1, 0, 0, nullptr, 0u, 0.f};
+  const int N = g.C;
   hipStream_t st = (hipStream_t)stream;
-  if (N <= 32) {
-    const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
-    hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, al, bl, ep, K, tm);
-  } else {
-    const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
-    hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, al, bl, ep, K, tm);
-  }
+  const int o_vec = (g.O % 4 == 0) && al16(dy) && al16(w);
+  for (int ph = 0; ph < g.sh; ++ph)
+    for (int pw = 0; pw < g.sw; ++pw) {
+      const int Hq = (g.H - ph + g.sh - 1) / g.sh, Wq = (g.W - pw + g.sw - 1) / g.sw;
+      if (Hq <= 0 || Wq <= 0) continue;
+      const int nR = ph < g.kh ? (g.kh - ph + g.sh - 1) / g.sh : 0, nS = pw < g.kw ? (g.kw - pw + g.sw - 1) / g.sw : 0;
+      const int M = g.B * Hq * Wq, K = nR * nS * g.O;     // K == 0 (stride > kernel): the class is written as zeros
+      const int nRd = nR > 0 ? nR : 1;
+      const AsrDiv dHq = asr_make_div(Hq), dWq = asr_make_div(Wq), dO = asr_make_div(g.O), dnR = asr_make_div(nRd);
+      DyClassLoader<1> av{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR};
+      DyClassLoader<0> as{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR};
+      WtClassLoader<1> bv{w, g, ph, pw, nRd, N, K, dO, dnR};
+      WtClassLoader<0> bs{w, g, ph, pw, nRd, N, K, dO, dnR};
+      const int k_per_j = (K > 0 && (nR * g.O) % 4 == 0) ? nR * g.O : 0;   // K ranges start on a float4 boundary
+      GemmEpilogue ep{dx, (long)N, M, N, 1.f, nullptr, nullptr, 1, 0, 0, nullptr, 0u, 0.f, 1, Hq, Wq, g.sh, g.sw, ph, pw, g.H, g.W};
+      if (N <= 32) {
+        const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
+        if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bv, ep, K, tm, k_per_j);
+        else hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bs, ep, K, tm, k_per_j);
+      } else {
+        const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
+        if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bv, ep, K, tm, k_per_j);
+        else hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bs, ep, K, tm, k_per_j);
+      }
+    }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

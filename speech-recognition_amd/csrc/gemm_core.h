@@ -15,17 +15,43 @@
 
 #define GEMM_BK 32
 
-// ---- loader policies: fetch4(r, c, v) reads stored[r][c..c+3] with zero fill outside [R, Cc)
+// ---- loader policies.  A loader presents a stored matrix [R][Cc] in two phases so that the main loop can
+// hoist whatever does not change along K out of it:
+//   Row row(r)   - everything derived from the stored row index      (address base, validity)
+//   Col col(c)   - everything derived from the stored column c (a multiple of 4)
+//   fetch4(row, col, v) reads stored[r][c..c+3] with zero fill outside [R, Cc)
+// For an operand whose K index is the stored column (A with TA == 0, B with TB == 1) the rows are fixed per
+// thread and only col() is evaluated per K tile; for the transposed storage it is the other way round.
+// Divisions by run-time constants use AsrDiv (multiply-high + one correction, exact for all 32-bit x).
+struct AsrDiv {
+  uint32_t d, magic;   // magic = floor(2^32 / d) (d >= 2), unused for d == 1
+  __device__ __forceinline__ void divmod(uint32_t x, uint32_t& q, uint32_t& r) const {
+    if (d == 1) { q = x; r = 0; return; }
+    q = __umulhi(x, magic);
+    r = x - q * d;
+    if (r >= d) { q += 1; r -= d; }
+  }
+};
+static inline AsrDiv asr_make_div(uint32_t d) {
+  AsrDiv v;
+  v.d = d ? d : 1;
+  v.magic = v.d > 1 ? (uint32_t)(4294967296ULL / v.d) : 0u;
+  return v;
+}
+
 // FastLoader: 16-byte aligned rows, Cc % 4 == 0 - branch-free (clamped address + select).
 struct FastLoader {
   const float* p;
   long ld;
   int R, Cc;
+  struct Row { long off; int ok; };
+  struct Col { int cc; int ok; };
   __device__ __forceinline__ void offset_z(long da, long) { p += da; }
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
-    const int rr = min(r, R - 1), cc = min(c, Cc - 4);
-    const float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + cc);
-    const bool ok = (r < R) && (c < Cc);
+  __device__ __forceinline__ Row row(int r) const { return Row{(long)min(r, R - 1) * ld, r < R}; }
+  __device__ __forceinline__ Col col(int c) const { return Col{min(c, Cc - 4), c < Cc}; }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    const float4 t = *reinterpret_cast<const float4*>(p + rw.off + cl.cc);
+    const bool ok = rw.ok && cl.ok;
     v[0] = ok ? t.x : 0.f; v[1] = ok ? t.y : 0.f; v[2] = ok ? t.z : 0.f; v[3] = ok ? t.w : 0.f;
   }
 };
@@ -37,12 +63,18 @@ struct FastScaledLoader {
   int R, Cc;
   const float* scale;
   uint32_t magic;
+  struct Row { long off; long soff; int ok; };
+  struct Col { int cc; int ok; };
   __device__ __forceinline__ void offset_z(long da, long ds) { p += da; scale += ds; }
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
-    const int rr = min(r, R - 1), cc = min(c, Cc - 4);
-    const float4 t = *reinterpret_cast<const float4*>(p + (long)rr * ld + cc);
-    const float4 s = *reinterpret_cast<const float4*>(scale + (long)__umulhi((uint32_t)rr, magic) * Cc + cc);
-    const bool ok = (r < R) && (c < Cc);
+  __device__ __forceinline__ Row row(int r) const {
+    const int rr = min(r, R - 1);
+    return Row{(long)rr * ld, (long)__umulhi((uint32_t)rr, magic) * Cc, r < R};
+  }
+  __device__ __forceinline__ Col col(int c) const { return Col{min(c, Cc - 4), c < Cc}; }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    const float4 t = *reinterpret_cast<const float4*>(p + rw.off + cl.cc);
+    const float4 s = *reinterpret_cast<const float4*>(scale + rw.soff + cl.cc);
+    const bool ok = rw.ok && cl.ok;
     v[0] = ok ? t.x * s.x : 0.f; v[1] = ok ? t.y * s.y : 0.f; v[2] = ok ? t.z * s.z : 0.f; v[3] = ok ? t.w * s.w : 0.f;
   }
 };
@@ -55,7 +87,12 @@ struct PlainLoader {
   int vec_ok;      // base and ld 16-byte aligned
   const float* scale;  // optional group scale [R / rpg][Cc]
   int rpg;
-  __device__ __forceinline__ void fetch4(int r, int c, float (&v)[4]) const {
+  struct Row { int r; };
+  struct Col { int c; };
+  __device__ __forceinline__ Row row(int r) const { return Row{r}; }
+  __device__ __forceinline__ Col col(int c) const { return Col{c}; }
+  __device__ __forceinline__ void fetch4(const Row& rw, const Col& cl, float (&v)[4]) const {
+    const int r = rw.r, c = cl.c;
     if (r < R && c + 3 < Cc && vec_ok) {
       const float4 t = *reinterpret_cast<const float4*>(p + (long)r * ld + c);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -86,7 +123,17 @@ struct GemmEpilogue {
   const uint32_t* drop_seed;
   uint32_t drop_stream;
   float drop_rate;
-  __device__ __forceinline__ void put(int r, int c, float v) const {
+  // optional row remap (conv data-gradient by stride class): logical row (b, wq, hq) -> stored row
+  // (b, hq*sh + ph, wq*sw + pw) of a [B, H, W] grid
+  int rm_on, rm_Hq, rm_Wq, rm_sh, rm_sw, rm_ph, rm_pw, rm_H, rm_W;
+  // stored row of logical row r (evaluated once per row by the caller, not once per element)
+  __device__ __forceinline__ long map_row(int r) const {
+    if (!rm_on) return r;
+    const int rc = min(r, M - 1);
+    const int hq = rc % rm_Hq, t = rc / rm_Hq, wq = t % rm_Wq, b = t / rm_Wq;
+    return ((long)b * rm_H + (long)hq * rm_sh + rm_ph) * rm_W + (long)wq * rm_sw + rm_pw;
+  }
+  __device__ __forceinline__ void put(int r, long rr, int c, float v) const {
     if (r >= M || c >= N) return;
     v *= alpha;
     if (bias != nullptr) v += bias[c];
@@ -96,7 +143,7 @@ struct GemmEpilogue {
       const AsrRngKey key = asr_rng_key(drop_seed[0], drop_stream);
       v *= asr_drop_mult(key, (uint32_t)((long)r * N + c), asr_drop_threshold(drop_rate), 1.f / (1.f - drop_rate));
     }
-    float* dst = C + (long)r * ldc + c;
+    float* dst = C + rr * ldc + c;
     if (mode == 0) *dst = v;
     else if (mode == 1) *dst += v;
     else atomicAdd(dst, v);
@@ -113,9 +160,9 @@ struct GemmEpilogue {
 //   k-contiguous operand : float4 granules [k/4][mn ^ (k/4)]  - b128 stores from the coalesced global
 //                          load mapping and b128 reads, both conflict-free through the XOR swizzle
 //   mn-contiguous operand: [k][mn] floats, b128 stores, b32 reads (consecutive lanes -> consecutive mn)
-template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
+template <int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N, int BK_ = GEMM_BK>
 struct GemmTile {
-  static constexpr int BK = GEMM_BK;
+  static constexpr int BK = BK_;   // 32, or 64 for the narrow-N conv tiles (twice the MFMAs between barriers)
   static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   static constexpr int MI = WM / 32, NI = WN / 32;
   static constexpr int A_KC = (TA == 0);  // A has k contiguous
@@ -126,6 +173,7 @@ struct GemmTile {
   static constexpr int B_V4 = BN * BK / 4 / 256;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
+  static_assert(256 % (BM / 4) == 0 && 256 % (BN / 4) == 0 && 256 % (BK / 4) == 0, "per-thread fixed fetch column");
 
   template <class AL, class BL>
   static __device__ __forceinline__ void run(const AL& al, const BL& bl, const GemmEpilogue& ep, int kbeg, int kend,
@@ -143,18 +191,37 @@ struct GemmTile {
     float4* As4 = reinterpret_cast<float4*>(As);
     float4* Bs4 = reinterpret_cast<float4*>(Bs);
 
+    // the index that is fixed per thread along K (stored row for a k-contiguous operand, stored column
+    // otherwise) is decoded once; the other one once per K tile
+    typename AL::Row arow[A_KC ? A_V4 : 1];
+    typename BL::Row brow[B_KC ? B_V4 : 1];
+    // (256 threads and BM/4, BN/4, BK/4 all divide 256: the fixed column of a thread is the same for all its fetches)
+    const typename AL::Col acol = al.col(m0 + 4 * (tid % (BM / 4)));
+    const typename BL::Col bcol = bl.col(n0 + 4 * (tid % (BN / 4)));
+    if (A_KC) {
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i) arow[i] = al.row(m0 + (tid + i * 256) / (BK / 4));
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) brow[i] = bl.row(n0 + (tid + i * 256) / (BK / 4));
+    }
     auto gload = [&](int k0) {
+      if (A_KC) {
+        const typename AL::Col kc = al.col(k0 + 4 * (tid % (BK / 4)));
 #pragma unroll
-      for (int i = 0; i < A_V4; ++i) {
-        const int f = tid + i * 256;
-        if (A_KC) { const int r = f / (BK / 4), q = f % (BK / 4); al.fetch4(m0 + r, k0 + 4 * q, ra[i]); }
-        else      { const int r = f / (BM / 4), q = f % (BM / 4); al.fetch4(k0 + r, m0 + 4 * q, ra[i]); }
+        for (int i = 0; i < A_V4; ++i) al.fetch4(arow[i], kc, ra[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) al.fetch4(al.row(k0 + (tid + i * 256) / (BM / 4)), acol, ra[i]);
       }
+      if (B_KC) {
+        const typename BL::Col kc = bl.col(k0 + 4 * (tid % (BK / 4)));
 #pragma unroll
-      for (int i = 0; i < B_V4; ++i) {
-        const int f = tid + i * 256;
-        if (B_KC) { const int r = f / (BK / 4), q = f % (BK / 4); bl.fetch4(n0 + r, k0 + 4 * q, rb[i]); }
-        else      { const int r = f / (BN / 4), q = f % (BN / 4); bl.fetch4(k0 + r, n0 + 4 * q, rb[i]); }
+        for (int i = 0; i < B_V4; ++i) bl.fetch4(brow[i], kc, rb[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) bl.fetch4(bl.row(k0 + (tid + i * 256) / (BN / 4)), bcol, rb[i]);
       }
     };
     auto lstore = [&]() {
@@ -224,12 +291,11 @@ struct GemmTile {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long srow = ep.map_row(row);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int col = n0 + wn * WN + j * 32 + l31;
-          ep.put(row, col, acc[i][j][r]);
-        }
+        for (int j = 0; j < NI; ++j) ep.put(row, srow, n0 + wn * WN + j * 32 + l31, acc[i][j][r]);
+      }
   }
 };
