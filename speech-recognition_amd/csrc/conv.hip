@@ -162,11 +162,29 @@ __global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader<VEC> 
   T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
+// all stride classes of one data-gradient in ONE launch (class = blockIdx.z): their tiles fill the chip
+// together instead of leaving a ragged tail per class
+#define CONV_MAX_CLASSES 4
+template <int VEC>
+struct ConvClass {
+  DyClassLoader<VEC> al;
+  WtClassLoader<VEC> bl;
+  GemmEpilogue ep;
+  int K, tiles_m, tiles, k_per_j;
+};
+template <int VEC>
+struct ConvClassSet { ConvClass<VEC> c[CONV_MAX_CLASSES]; };
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(DyClassLoader<VEC> al, WtClassLoader<VEC> bl, GemmEpilogue ep, int K, int tiles_m, int k_per_j) {
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs) {
   using T = GemmTile<0, 1, BM, BN, WAVES_M, WAVES_N, BK>;
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
+  const ConvClass<VEC>& cc = cs.c[blockIdx.z];
+  if ((int)blockIdx.x >= cc.tiles) return;
+  DyClassLoader<VEC> al = cc.al;
+  WtClassLoader<VEC> bl = cc.bl;
+  const int K = cc.K, tiles_m = cc.tiles_m, k_per_j = cc.k_per_j;
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
   int kbeg = 0, kend = K;
   if (k_per_j > 0) {   // taps j outside [wq - (Wo-1), wq] read only zeros for every row of this tile: skip them
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(DyClassLoader<VEC> a
       bl.Cc = kend;
     }
   }
-  T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  T::run(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 static int conv_geom(const asr_conv_desc* d, ConvGeom* g) {
@@ -273,6 +291,21 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
   const int N = g.C;
   hipStream_t st = (hipStream_t)stream;
   const int o_vec = (g.O % 4 == 0) && al16(dy) && al16(w);
+  const bool narrow = N <= 32;
+  const int BMh = narrow ? 256 : 128, BNh = narrow ? 32 : 64;
+  // classes in chunks of CONV_MAX_CLASSES per launch (sh * sw <= 4 for every shipped model: one launch)
+  ConvClassSet<1> sv{};
+  ConvClassSet<0> ss{};
+  int n = 0, max_tiles = 0;
+  auto flush = [&]() {
+    if (n == 0) return;
+    dim3 grid((unsigned)max_tiles, 1, (unsigned)n);
+    if (narrow && o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
+    else if (narrow) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, ss);
+    else if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, sv);
+    else hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, ss);
+    n = 0; max_tiles = 0;
+  };
   for (int ph = 0; ph < g.sh; ++ph)
     for (int pw = 0; pw < g.sw; ++pw) {
       const int Hq = (g.H - ph + g.sh - 1) / g.sh, Wq = (g.W - pw + g.sw - 1) / g.sw;
@@ -281,22 +314,17 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
       const int M = g.B * Hq * Wq, K = nR * nS * g.O;     // K == 0 (stride > kernel): the class is written as zeros
       const int nRd = nR > 0 ? nR : 1;
       const AsrDiv dHq = asr_make_div(Hq), dWq = asr_make_div(Wq), dO = asr_make_div(g.O), dnR = asr_make_div(nRd);
-      DyClassLoader<1> av{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR};
-      DyClassLoader<0> as{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR};
-      WtClassLoader<1> bv{w, g, ph, pw, nRd, N, K, dO, dnR};
-      WtClassLoader<0> bs{w, g, ph, pw, nRd, N, K, dO, dnR};
       const int k_per_j = (K > 0 && (nR * g.O) % 4 == 0) ? nR * g.O : 0;   // K ranges start on a float4 boundary
+      const int tm = asr_cdiv(M, BMh), tn = asr_cdiv(N, BNh);
       GemmEpilogue ep{dx, (long)N, M, N, 1.f, nullptr, nullptr, 1, 0, 0, nullptr, 0u, 0.f, 1, Hq, Wq, g.sh, g.sw, ph, pw, g.H, g.W};
-      if (N <= 32) {
-        const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
-        if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bv, ep, K, tm, k_per_j);
-        else hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bs, ep, K, tm, k_per_j);
-      } else {
-        const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
-        if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bv, ep, K, tm, k_per_j);
-        else hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bs, ep, K, tm, k_per_j);
-      }
+      sv.c[n] = ConvClass<1>{DyClassLoader<1>{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR}, WtClassLoader<1>{w, g, ph, pw, nRd, N, K, dO, dnR}, ep,
+                             K, tm, tm * tn, k_per_j};
+      ss.c[n] = ConvClass<0>{DyClassLoader<0>{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR}, WtClassLoader<0>{w, g, ph, pw, nRd, N, K, dO, dnR}, ep,
+                             K, tm, tm * tn, k_per_j};
+      max_tiles = tm * tn > max_tiles ? tm * tn : max_tiles;
+      if (++n == CONV_MAX_CLASSES) flush();
     }
+  flush();
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
