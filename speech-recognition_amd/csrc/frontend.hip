@@ -7,6 +7,7 @@
 // (+2 halo frames) and every output element written once; the twiddle table (window folded in,
 // stored in MFMA fragment order) and the mel matrix stay L2 resident.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -26,6 +27,7 @@ struct FeArgs {
   int B, n_max, T_out;
   int L, step, bins, nmel, C;
   int KS, NBT, pad, seg_len, seg_floats, PLD;
+  int sym, KS2;                 // sym: fft_length == frame_length (even): cos/sin symmetry folds the frame, KS2 = DFT k-steps
   float eps;
   int sa_enable, sa_F, sa_mF, sa_T, sa_mT;
   float sa_p;
@@ -90,17 +92,36 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
     f32x4 ac[MT], as[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { ac[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; as[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const float* twc = a.tw + (long)(bt * 2 + 0) * a.KS * 64 + lane;
-    const float* tws = a.tw + (long)(bt * 2 + 1) * a.KS * 64 + lane;
-    for (int ks = 0; ks < a.KS; ++ks) {
-      const float bc = twc[ks * 64], bs = tws[ks * 64];
-      const int k = 4 * ks + lq;
-      const int koff = k + a.pad * (k / a.step);
+    const float* twc = a.tw + (long)(bt * 2 + 0) * a.KS2 * 64 + lane;
+    const float* tws = a.tw + (long)(bt * 2 + 1) * a.KS2 * 64 + lane;
+    if (a.sym) {
+      // cos(2 pi k (L-n)/L) = cos(2 pi k n/L), sin(...) = -sin(...), and the periodic Hann window is symmetric
+      // too (w[n] = w[L-n], w[0] = 0): pair samples n and L-n, n = 1 .. L/2 -> half the MFMAs.
+      //   Re[k] = sum_n (x[n] + x[L-n]) * w[n] cos(2 pi k n / L)   (the n = L/2 entry of the table is halved)
+      //   Im[k] = sum_n (x[n] - x[L-n]) * w[n] sin(2 pi k n / L)
+      for (int ks = 0; ks < a.KS2; ++ks) {
+        const float bc = twc[ks * 64], bs = tws[ks * 64];
+        const int n = min(4 * ks + lq + 1, a.L / 2), n2 = a.L - n;   // entries past L/2 carry zero twiddles
+        const int o1 = n + a.pad * (n / a.step), o2 = n2 + a.pad * (n2 / a.step);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float av = seg[(m * 16 + li) * fstride + koff];
-        ac[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bc, ac[m], 0, 0, 0);
-        as[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bs, as[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) {
+          const float* row = seg + (m * 16 + li) * fstride;
+          const float x1 = row[o1], x2 = row[o2];
+          ac[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1 + x2, bc, ac[m], 0, 0, 0);
+          as[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1 - x2, bs, as[m], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int ks = 0; ks < a.KS2; ++ks) {
+        const float bc = twc[ks * 64], bs = tws[ks * 64];
+        const int k = 4 * ks + lq;
+        const int koff = k + a.pad * (k / a.step);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float av = seg[(m * 16 + li) * fstride + koff];
+          ac[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bc, ac[m], 0, 0, 0);
+          as[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bs, as[m], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -162,6 +183,8 @@ static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a, int FE_FR = FE_FR_MAX
   a->L = c->frame_length; a->step = c->frame_step; a->bins = c->fft_length / 2 + 1; a->nmel = c->num_mel_bins;
   a->C = c->use_delta ? 3 : 1;
   a->KS = asr_cdiv(a->L, 4); a->NBT = asr_cdiv(a->bins, 16);
+  a->sym = (c->fft_length == c->frame_length && c->frame_length % 2 == 0) ? 1 : 0;
+  a->KS2 = a->sym ? asr_cdiv(a->L / 2, 4) : a->KS;
   a->pad = ((2 - a->step) % 32 + 32) % 32;
   a->seg_len = (FE_FR - 1) * a->step + 4 * a->KS;
   a->seg_floats = a->seg_len + a->pad * (a->seg_len / a->step + 1);
@@ -181,7 +204,7 @@ extern "C" int asr_logmel_table_sizes(const asr_logmel_cfg* cfg, long* n_tw, lon
   FeArgs a{};
   int rc = fe_geometry(cfg, &a);
   if (rc) return rc;
-  *n_tw = (long)a.NBT * 2 * a.KS * 64;
+  *n_tw = (long)a.NBT * 2 * a.KS2 * 64;
   *n_melw = (long)a.bins * a.nmel;
   *n_range = 2L * a.nmel;
   return ASR_OK;
@@ -196,18 +219,30 @@ extern "C" int asr_logmel_build_tables(const asr_logmel_cfg* cfg, float* tw, flo
   // twiddles with the periodic Hann window folded in ([TF-sem] tf.signal.hann_window(periodic=True))
   for (int bt = 0; bt < a.NBT; ++bt)
     for (int cs = 0; cs < 2; ++cs)
-      for (int ks = 0; ks < a.KS; ++ks)
+      for (int ks = 0; ks < a.KS2; ++ks)
         for (int lane = 0; lane < 64; ++lane) {
-          const int k = 4 * ks + (lane >> 4), bin = bt * 16 + (lane & 15);
+          const int bin = bt * 16 + (lane & 15);
           double v = 0.0;
-          // [TF-sem] tf.signal.stft: rfft crops the windowed frame to fft_length samples when it is shorter
-          if (k < a.L && k < cfg->fft_length && bin < a.bins) {
-            const double w = 0.5 - 0.5 * cos(2.0 * PI * k / a.L);
-            const long kb = ((long)k * bin) % cfg->fft_length;
-            const double ang = 2.0 * PI * (double)kb / cfg->fft_length;
-            v = w * (cs == 0 ? cos(ang) : sin(ang));
+          if (a.sym) {
+            const int n = 4 * ks + (lane >> 4) + 1;        // sample pair (n, L - n), n = 1 .. L/2
+            if (n <= a.L / 2 && bin < a.bins) {
+              const double w = 0.5 - 0.5 * cos(2.0 * PI * n / a.L);
+              const long kb = ((long)n * bin) % a.L;
+              const double ang = 2.0 * PI * (double)kb / a.L;
+              v = w * (cs == 0 ? cos(ang) : sin(ang));
+              if (n == a.L / 2) v = cs == 0 ? 0.5 * v : 0.0;   // its own partner: x + x = 2x, x - x = 0
+            }
+          } else {
+            const int k = 4 * ks + (lane >> 4);
+            // [TF-sem] tf.signal.stft: rfft crops the windowed frame to fft_length samples when it is shorter
+            if (k < a.L && k < cfg->fft_length && bin < a.bins) {
+              const double w = 0.5 - 0.5 * cos(2.0 * PI * k / a.L);
+              const long kb = ((long)k * bin) % cfg->fft_length;
+              const double ang = 2.0 * PI * (double)kb / cfg->fft_length;
+              v = w * (cs == 0 ? cos(ang) : sin(ang));
+            }
           }
-          tw[((long)(bt * 2 + cs) * a.KS + ks) * 64 + lane] = (float)v;
+          tw[((long)(bt * 2 + cs) * a.KS2 + ks) * 64 + lane] = (float)v;
         }
   // [TF-sem] tf.signal.linear_to_mel_weight_matrix: HTK mel, triangles on the mel axis, DC row zero
   auto hz2mel = [](double f) { return 1127.0 * log1p(f / 700.0); };
@@ -247,11 +282,20 @@ extern "C" int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio
   FeArgs a{};
   int MT = 4, rc = 0;
   size_t smem = 0;
-  for (; MT >= 1; MT >>= 1) {            // fewer frames per workgroup when long frames would not fit in LDS
-    rc = fe_geometry(cfg, &a, 16 * MT);
-    if (rc) return rc;
-    smem = fe_smem_bytes(a, 16 * MT);
-    if (smem <= 160 * 1024) break;
+  // Frames per workgroup: the kernel's phases (stage, DFT, mel + log, delta + store) run one after another
+  // inside a workgroup, so several workgroups per CU (<= 40 KiB of LDS each: measured 170 us at 16 frames per
+  // workgroup vs 194 at 32 and 312 at 64 for the libri configuration) overlap them; frame parameters too long
+  // for that fall back to whatever fits the 160 KiB of a CU.
+  const int env_mt = getenv("ASR_LOGMEL_MT") ? atoi(getenv("ASR_LOGMEL_MT")) : 0;   // tuning aid: 4, 2 or 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const size_t limit = pass == 0 ? 40 * 1024 : 160 * 1024;
+    for (MT = env_mt ? env_mt : 4; MT >= 1; MT >>= 1) {
+      rc = fe_geometry(cfg, &a, 16 * MT);
+      if (rc) return rc;
+      smem = fe_smem_bytes(a, 16 * MT);
+      if (smem <= limit || (env_mt && smem <= 160 * 1024)) break;
+    }
+    if (MT >= 1) break;
   }
   ASR_CHECK(MT >= 1, ASR_ERR_SHAPE, "asr_logmel_features: frame parameters need %zu B of LDS (> 160 KiB)", smem);
   a.audio = audio; a.n_samples = n_samples; a.tw = tw; a.melw = melw; a.melrange = melrange; a.seed = seed; a.out = out;
