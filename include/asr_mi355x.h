@@ -335,6 +335,20 @@ long asr_rnn_persist_bwd_ws_floats(int B, int H, int ndir);
 int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
 
+/* The same two attention steps as ONE launch each (asr_attn_step_fwd / asr_attn_step_bwd are two): the T axis
+ * is cut into chunks, every (batch row, chunk) workgroup publishes chunk-local softmax statistics and partial
+ * sums, and the last one to arrive at an agent-scope ticket combines them.  Results equal to fp32 rounding
+ * (the softmax is evaluated per chunk and rescaled).  scratch: asr_attn_fused_ws_floats() floats; tickets:
+ * B uint32 words that are zero when first used and are only ever passed to these two functions (each call adds
+ * the same constant per row, so they never need resetting - safe to replay from a hipGraph).  Supported when
+ * asr_attn_fused_supported(): Hd % 4 == 0, D % 4 == 0, T <= 512, 16-byte aligned rows. */
+long asr_attn_fused_ws_floats(int B, int Hd, int D);
+int asr_attn_fused_supported(int T, int Hd, int D);
+int asr_attn_fused_fwd(const float* h, long ldh, const float* Kq, const float* s0, const uint8_t* mask, const float* enc, int B,
+                       int T, int Hd, int D, float* scratch, uint32_t* tickets, float* p, float* ctx, long ldctx, void* stream);
+int asr_attn_fused_bwd(const float* dctx, long lddctx, const float* p, const float* Kq, const float* enc, int B, int T, int Hd,
+                       int D, float* scratch, uint32_t* tickets, float* ds, float* dh, long lddh, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Greedy decoding (search.py).  All state stays on the device: a decode needs no host round trip per step.
  * asr_greedy_update - one step of LAS_Searcher.greedy_search (search.py:41-55) on logits [B, V]:

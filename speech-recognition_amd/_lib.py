@@ -161,6 +161,10 @@ SIGNATURES = {
     "asr_ctc_loss": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int,
                                C.c_float, _P]),
     "asr_mask_rows": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, _P, c_long, _P]),
+    "asr_attn_fused_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_attn_fused_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "asr_attn_fused_fwd": (C.c_int, [_P, c_long, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, c_long, _P]),
+    "asr_attn_fused_bwd": (C.c_int, [_P, c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, c_long, C.c_int, _P]),
     "asr_greedy_update": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "asr_ctc_greedy": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "asr_audio_info": (C.c_int, [C.c_char_p, c_long, C.c_int, C.POINTER(AudioInfo)]),

@@ -15,6 +15,7 @@ Decoder-side sequences are stored step-major ([U, B, ...]) so that a step's slic
 encoder-side tensors are batch-major ([B, T', ...]) like the reference.
 """
 import math
+import os
 import random
 from collections import OrderedDict
 from typing import List, Optional, Tuple
@@ -241,6 +242,11 @@ class LAS(ModelProto):
                 d["h"], d["c"] = f(U, B, Hd), f(U, B, Hd)
             ws.dec.append(d)
         ws.e, ws.p, ws.ctx = f(B, T2), f(U, B, T2), f(U, B, 2 * He)
+        # ASR_FUSED_ATTENTION=1 selects the one-launch attention steps (attention_fused.hip).  Off by default:
+        # measured on las_small they take 17.5 us per step against 5.2 + 9.0 us for the two-kernel steps - the
+        # in-launch combine (agent release/acquire + a serial last-arriver pass) costs more than the launch it saves
+        fused = os.environ.get("ASR_FUSED_ATTENTION", "0") == "1" and ops.attn_fused_supported(T2, Hd, 2 * He)
+        ws.attn_fused = ops.attn_fused_ws(B, Hd, 2 * He, dev) if fused else None
         ws.yd, ws.logits = f(U * B, Hd), f(U * B, V)
         ws.stats = torch.zeros(4, device=dev)
         # backward
@@ -358,7 +364,10 @@ class LAS(ModelProto):
         p, B, Hd, He, rt = self.store.p, ws.B, self.Hd, self.He, self.rt
         rate = self.dropout if training else 0.0
         base = R.STREAM_DEC + R.DEC_STREAMS_PER_STEP * (i + step_offset)
-        ops.attn_step_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.e, ws.p[i], ws.ctx[i])
+        if ws.attn_fused is not None:      # one launch per step
+            ops.attn_fused_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.attn_fused, ws.p[i], ws.ctx[i])
+        else:
+            ops.attn_step_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.e, ws.p[i], ws.ctx[i])
         for j, cell in enumerate(self.dec_cells):
             h_in, c_in, h_out, c_out = self._cell_states(ws, j, i)
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"
@@ -521,7 +530,10 @@ class LAS(ModelProto):
             lin.srcB = ops.back_src(ws.dec[0]["saved"][i], W0[Hd:], rt, Hd, "input", (rate, base + 2, Hd + 2 * He, Hd))
             lin.out, lin.out_ld = ws.dctx[i].data_ptr(), ws.dctx[i].stride(0)
             ops.rnn_cell_bwd(rt, B, [lin], seed)
-            ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False)
+            if ws.attn_fused is not None:
+                ops.attn_fused_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.attn_fused, ws.ds[i], ws.dh_attn, accumulate=False)
+            else:
+                ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False)
         # gradient wrt the decoder's initial states (= listener state projections)
         lin = _lib.RnnStepBwd()
         lin.n_units = Hd

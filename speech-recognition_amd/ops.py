@@ -505,6 +505,32 @@ def attn_step_bwd(dctx, p, Kq, enc, dp, ds, dh, accumulate):
                                   dh.stride(0), int(accumulate), _stream()))
 
 
+def attn_fused_supported(T, Hd, D):
+    return bool(lib().asr_attn_fused_supported(T, Hd, D))
+
+
+def attn_fused_ws(B, Hd, D, device="cuda"):
+    """(scratch f32, tickets i32 zeros) for attn_fused_fwd / attn_fused_bwd."""
+    return (torch.empty(int(lib().asr_attn_fused_ws_floats(B, Hd, D)), device=device, dtype=torch.float32),
+            torch.zeros(B, device=device, dtype=torch.int32))
+
+
+def attn_fused_fwd(h, Kq, s0, mask, enc, fws, p, ctx):
+    """attn_step_fwd in one launch; fws from attn_fused_ws."""
+    B, T, Hd = Kq.shape
+    D = enc.shape[2]
+    check(lib().asr_attn_fused_fwd(_p(h), h.stride(0), _p(Kq), _p(s0), _p(mask), _p(enc), B, T, Hd, D, _p(fws[0]), _p(fws[1]), _p(p),
+                                   _p(ctx), ctx.stride(0), _stream()))
+
+
+def attn_fused_bwd(dctx, p, Kq, enc, fws, ds, dh, accumulate):
+    """attn_step_bwd in one launch; fws from attn_fused_ws."""
+    B, T, Hd = Kq.shape
+    D = enc.shape[2]
+    check(lib().asr_attn_fused_bwd(_p(dctx), dctx.stride(0), _p(p), _p(Kq), _p(enc), B, T, Hd, D, _p(fws[0]), _p(fws[1]), _p(ds),
+                                   _p(dh), dh.stride(0), int(accumulate), _stream()))
+
+
 def softmax_xent(logits, labels, stats, ignore_index=0, write_grad=True, grad_scale=1.0):
     """logits [R, V] overwritten with the gradient; stats (3 floats) must be pre-zeroed."""
     R, V = logits.shape

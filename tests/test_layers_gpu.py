@@ -192,6 +192,49 @@ def test_attention_step_forward_backward(B, T, Hd, D):
     assert_close(dh - 1.0, gh, 1e-4, "dh through the scores")
 
 
+@pytest.mark.parametrize("B,T,Hd,D", [(5, 13, 128, 128), (43, 33, 256, 512), (3, 111, 16, 32), (2, 2, 4, 4), (4, 249, 256, 512), (32, 499, 64, 128)])
+def test_fused_attention_step_matches_oracle_and_two_kernel_path(B, T, Hd, D):
+    """One-launch attention steps (chunked softmax + last-arriver combine): same oracle, same tolerances as the
+    two-kernel path, several calls in a row on the same ticket words (as a captured decoder loop does), fully
+    masked chunks included."""
+    ops = _ops()
+    assert ops.attn_fused_supported(T, Hd, D)
+    g = torch.Generator().manual_seed(B * T + Hd + 1)
+    enc = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = torch.randn(B, T, generator=g) > -0.5
+    mask[:, 0] = True
+    if T > 40:
+        mask[0, 35:] = False                                     # whole chunks masked (a padded clip)
+    s = 1.0 / np.sqrt(Hd)
+    Wq = torch.randn(Hd, Hd, generator=g, dtype=torch.float64) * s
+    bq = torch.randn(Hd, generator=g, dtype=torch.float64) * 0.1
+    Wk = torch.randn(D, Hd, generator=g, dtype=torch.float64) / np.sqrt(D)
+    bk = torch.randn(Hd, generator=g, dtype=torch.float64) * 0.1
+    K = enc @ Wk + bk
+    Kq, s0 = K @ Wq.T, K @ bq
+    encg, Kqg, s0g, mg = gpu(enc), gpu(Kq), gpu(s0), mask.to(torch.uint8).cuda()
+    fws = ops.attn_fused_ws(B, Hd, D)
+    for rep in range(3):
+        h = torch.randn(B, Hd, generator=g, dtype=torch.float64, requires_grad=True)
+        ctx, p = L.attention(h, enc, enc, mask, Wq, bq, Wk, bk)
+        R = torch.randn(ctx.shape, generator=g, dtype=torch.float64)
+        gh, = torch.autograd.grad((ctx * R).sum(), h)
+        pg, ctxg = torch.full((B, T), float("nan"), device="cuda"), torch.full((B, D), float("nan"), device="cuda")
+        ops.attn_fused_fwd(gpu(h), Kqg, s0g, mg, encg, fws, pg, ctxg)
+        assert_close(pg, p, 2e-5, "attention probs (fused)")
+        assert_close(ctxg, ctx, 2e-5, "context (fused)")
+        e2, p2, c2 = torch.empty(B, T, device="cuda"), torch.empty(B, T, device="cuda"), torch.empty(B, D, device="cuda")
+        ops.attn_step_fwd(gpu(h), Kqg, s0g, mg, encg, e2, p2, c2)
+        assert_close(ctxg, c2, 5e-6, "context fused vs two-kernel")
+        ds, dh = torch.full((B, T), float("nan"), device="cuda"), torch.full((B, Hd), 1.0, device="cuda")
+        ops.attn_fused_bwd(gpu(R), pg, Kqg, encg, fws, ds, dh, accumulate=True)
+        assert_close(dh - 1.0, gh, 1e-4, "dh through the scores (fused)")
+        dp2, ds2, dh2 = torch.empty(B, T, device="cuda"), torch.empty(B, T, device="cuda"), torch.zeros(B, Hd, device="cuda")
+        ops.attn_step_bwd(gpu(R), pg, Kqg, encg, dp2, ds2, dh2, accumulate=False)
+        assert_close(ds, ds2, 1e-4, "ds fused vs two-kernel")      # p (dp - <p, dp>) cancels: absolute error of a few f32 ulps of dp
+    assert int(fws[1].min()) == int(fws[1].max()) == 6 * 8       # 3 forward + 3 backward calls, 8 chunks each
+
+
 @pytest.mark.parametrize("R_,V", [(10, 3000), (64, 16000), (3, 120), (2, 40000)])
 def test_softmax_cross_entropy_loss_accuracy_gradient(R_, V):
     ops = _ops()
