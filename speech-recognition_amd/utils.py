@@ -36,6 +36,20 @@ class LRScheduler:
                                self.warmup_steps, self.offset_steps)
 
 
+def levenshtein_distance(truth, hypothesis, normalize=True):
+    """utils.py:80-101: edit distance between two sequences (strings or lists), optionally divided by
+    len(truth) (the WER / CER of run/evaluate.py).  Two-row dynamic programme."""
+    n = len(hypothesis)
+    prev = list(range(n + 1))
+    for i in range(1, len(truth) + 1):
+        cur = [i] + [0] * n
+        ti = truth[i - 1]
+        for j in range(1, n + 1):
+            cur[j] = min(prev[j - 1] + (ti != hypothesis[j - 1]), prev[j] + 1, cur[j - 1] + 1)
+        prev = cur
+    return prev[n] / len(truth) if normalize else prev[n]
+
+
 def get_logger(name: str) -> logging.Logger:
     """utils.py:104-113."""
     logger = logging.getLogger(name)

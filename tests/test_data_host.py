@@ -227,6 +227,16 @@ def test_prefetch_preserves_order_and_propagates_errors():
         list(Dataset(boom).prefetch(2))
 
 
+def test_levenshtein_distance_reference_cases():
+    """The reference's known answers, tests/test_utils.py:18-34."""
+    from speech_recognition_amd.utils import levenshtein_distance
+    cases = [([], [], 0, False), (list("abc"), [], 3, False), ("hello", "hello", 0, False), (list("kitten"), list("sitten"), 1, False),
+             ("sunday", "saturday", 3, False), ([1, 2, 3], [4, 4, 4, 5], 4, False), (list("안녕하세요"), list("안녕? 해..?"), 6, False),
+             ("hi", "hello", 2.0, True), ("byebye", "yes", 2 / 3, True)]
+    for truth, hyp, dist, norm in cases:
+        assert levenshtein_distance(truth, hyp, norm) == dist
+
+
 def test_filter_and_slice_example():
     ds = Dataset.from_iterable([(np.zeros((n, 80, 1), np.float32), np.zeros(u, np.int32)) for n, u in [(10, 3), (30, 3), (10, 9)]])
     assert len(list(ds.apply(filter_example(20, 5)))) == 1                 # data.py:331-341
