@@ -68,7 +68,10 @@ static void launch_t(const GemmPlan& g, const AL& al, const BL& bl) {
     const long wgs = (long)asr_cdiv(d->M, bm) * asr_cdiv(d->N, bn) * z;
     const long rounds = (wgs + 255) / 256;                 // per-CU sequential tiles (at equal sharing)
     const double useful = (double)d->M * d->N * z;         // useful output elements
-    return tile_eff * useful / ((double)rounds * 256 * bm * bn);
+    // fewer than ~1.5 workgroups per CU: nothing overlaps a workgroup's prologue / epilogue (measured: proj
+    // 7968x512x512 56 -> 51 us, keys 32 -> 28 us, vocab dY 178 -> 165 us with the next smaller tile)
+    const double lonely = wgs < 384 ? 0.88 : 1.0;
+    return lonely * tile_eff * useful / ((double)rounds * 256 * bm * bn);
   };
   static const int forced = getenv("ASR_GEMM_TILE") ? atoi(getenv("ASR_GEMM_TILE")) : 0;   // tuning aid: 1..4
   if (forced == 1) { launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl); return; }
