@@ -30,7 +30,9 @@ PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
 WORKLOADS = {
-    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9,
+    # traffic: HBM-side bytes per step from the PMC passes of profiles/r01_las_small_pmc_hbm_traffic.txt
+    # (2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate, measured offline
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=2 * 7.34e9 + 4.12e9,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
@@ -280,7 +282,7 @@ def main():
                    "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "persistent_rnn": bool(_layers.PERSISTENT_RNN),
                    "final_loss": round(loss, 4)},
         "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": wl.get("traffic"),
                      "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"},
     }
     if args.workload == "las_small" and world == 1:
