@@ -102,5 +102,12 @@ class ModelProto(metaclass=ABCMeta):
                 raise ValueError(f"load_weights: {k} has shape {tuple(values[k].shape)} in {path}, the model needs {tuple(v.shape)}")
         self.load_state_dict({k: torch.from_numpy(values[k]) for k in mine})
 
+    def release_workspace(self, ws):
+        """Forget a workspace handed out by train_workspace()/forward() so that its buffers can be freed."""
+        cache = getattr(self, "_ws", None)
+        if cache:
+            for k in [k for k, v in cache.items() if v is ws]:
+                del cache[k]
+
     def weights_changed(self):
         """Re-derive any packed weight image (call after every optimizer step / weight load)."""

@@ -74,6 +74,7 @@ class TrainStep:
         self.world = strategy.world_size if strategy is not None else 1
         self.group = getattr(strategy, "group", None)
         self._shapes: Dict[tuple, dict] = {}
+        self.max_shapes = 16                       # input shapes kept alive (workspace + captured graphs each), least recently used evicted
         self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
         self.exchange = GradientExchange(self.world, self.group, self.stream)
         self.iterations = 0
@@ -82,7 +83,13 @@ class TrainStep:
     def _ctx(self, audio, n_samples, tokens):
         key = (tuple(audio.shape), tuple(tokens.shape))
         if key in self._shapes:
+            self._shapes[key] = self._shapes.pop(key)      # most recently used last
             return self._shapes[key]
+        if len(self._shapes) >= self.max_shapes:           # real data: every padded batch shape has its own buffers + graphs
+            self.synchronize()
+            old = self._shapes.pop(next(iter(self._shapes)))
+            self.model.release_workspace(old["ws"])
+            old.clear()
         dev = self.model.device
         c = dict(audio=torch.empty(audio.shape, dtype=torch.float32, device=dev),
                  n_samples=torch.empty(audio.shape[0], dtype=torch.int32, device=dev) if self.frontend else None,
