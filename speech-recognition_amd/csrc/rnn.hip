@@ -1,10 +1,10 @@
 // Recurrent cells for gfx950: Keras LSTM / GRU(reset_after) / SimpleRNN with K.rnn mask semantics
 // (las.py:62-126 BiRNN, las.py:259-262,285-288 decoder cells, deepspeech2.py:109-119).
 //
-// One launch = one time step (both directions of a BiRNN ride in blockIdx.z).  A launch boundary
-// on MI355X costs about what a hand-rolled grid barrier does (MI355X_MICROARCH price list rows
-// "boundary" vs "barrier-xcd") and cannot deadlock; the whole step sequence is meant to be
-// captured in a hipGraph by the caller.
+// This file: the ONE-LAUNCH-PER-TIME-STEP forward kernels (both directions of a BiRNN ride in
+// blockIdx.z) - used for the LAS decoder cells, and for whole layers whose shape the persistent
+// one-launch-per-layer kernel (rnn_persist.hip) does not take.  The step sequence is meant to be captured
+// in a hipGraph by the caller.
 //
 // Work split: workgroup (q, bt, dir) owns hidden units [4q, 4q+4) x batch rows [16bt, 16bt+16).
 // The per-step product  [16 x Ktot] x [Ktot x 16 gate columns]  runs on v_mfma_f32_16x16x4_f32 with
@@ -15,10 +15,7 @@
 // "slot" = one of the 16 packed gate columns: slot = 4*s + u, u = unit within the group,
 //   LSTM s = gate i,f,c~,o        GRU s = z, r, x-part of h~, recurrent part of h~        RNN s = 0 only.
 //
-// Backward step: gate gradients for the owned units, then the partial product
-// dA_partial[16 x Ktot] = dslots[16 x 16] x Wslice^T goes to a per-workgroup slab; whoever consumes
-// a gradient (the previous step's cell, or asr_slab_reduce) sums the slabs of all q.  No atomics,
-// bit-reproducible.
+// The backward step kernels live in rnn_bwd.hip (and rnn_persist_bwd.hip for whole layers).
 #include "common.h"
 
 #define CELL_LSTM 0
