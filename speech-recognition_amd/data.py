@@ -42,6 +42,17 @@ def _call(fn, element):
     return fn(*element) if isinstance(element, tuple) else fn(element)
 
 
+AUTOTUNE = -1     # tf.data.experimental.AUTOTUNE stand-in for map(num_parallel_calls=...)
+
+
+def _autotune_workers() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 class Dataset:
     """Lazy, re-iterable sequence of examples (nested tuples of numpy arrays)."""
 
@@ -57,7 +68,25 @@ class Dataset:
         return Dataset(lambda: iter(items))
 
     def map(self, fn, num_parallel_calls=None) -> "Dataset":
-        return Dataset(lambda: (_call(fn, e) for e in self))
+        """Apply fn to every example.  num_parallel_calls > 1 (or AUTOTUNE) runs fn on a thread pool with a
+        bounded window of examples in flight, results in input order (tf.data's deterministic parallel map).
+        Worth it for functions that release the GIL - the native audio decoders do."""
+        workers = _autotune_workers() if num_parallel_calls == AUTOTUNE else int(num_parallel_calls or 0)
+        if workers <= 1:
+            return Dataset(lambda: (_call(fn, e) for e in self))
+
+        def gen():
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                window = deque()
+                for e in self:
+                    window.append(pool.submit(_call, fn, e))
+                    if len(window) >= 4 * workers:
+                        yield window.popleft().result()
+                while window:
+                    yield window.popleft().result()
+        return Dataset(gen)
 
     def filter(self, fn) -> "Dataset":
         return Dataset(lambda: (e for e in self if _call(fn, e)))
@@ -262,17 +291,19 @@ def get_dataset(dataset_paths: str, file_format: str, sample_rate: int, tokenize
         random.shuffle(dataset_list)
     load = load_audio_file(sample_rate, file_format, resample)
 
-    def gen():
+    def rows():
         for tsv in dataset_list:
             base = os.path.dirname(os.path.abspath(tsv))
             with open(tsv, newline="", encoding="utf-8") as f:
-                rows = csv.reader(f, delimiter="\t", quoting=csv.QUOTE_NONE)
-                next(rows, None)                                   # header
-                for row in rows:
-                    if len(row) < 2:
-                        continue
-                    yield load(os.path.join(base, row[0])), np.asarray(tokenizer.tokenize(row[1]), np.int32)
-    return Dataset(gen)
+                reader = csv.reader(f, delimiter="\t", quoting=csv.QUOTE_NONE)
+                next(reader, None)                                 # header
+                for row in reader:
+                    if len(row) >= 2:
+                        yield os.path.join(base, row[0]), row[1]
+
+    # file read + decode (native code, GIL released) + tokenisation on a thread pool, order preserved
+    # (the reference maps load_example with AUTOTUNE parallelism inside each interleaved file, data.py:52-61)
+    return Dataset(rows).map(lambda path, text: (load(path), np.asarray(tokenizer.tokenize(text), np.int32)), num_parallel_calls=AUTOTUNE)
 
 
 def get_tfrecord_dataset(dataset_paths: str) -> Dataset:

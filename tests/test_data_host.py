@@ -217,6 +217,30 @@ def test_padded_batch_pads_with_zeros_and_reports_lengths():
     assert len(list(Dataset.from_iterable(ex).padded_batch(2, drop_remainder=True))) == 1
 
 
+def test_parallel_map_is_ordered_bounded_and_propagates_errors():
+    import threading
+    import time
+    from speech_recognition_amd.data import AUTOTUNE
+    seen = []
+    lock = threading.Lock()
+
+    def slow(a, t):
+        time.sleep(0.002 * (len(a) % 3))                                   # finish out of order
+        with lock:
+            seen.append(len(a))
+        return a * 2, t
+    out = [len(a) for a, _ in _toy(100).map(slow, num_parallel_calls=4)]
+    assert out == list(range(1, 101)) and sorted(seen) == out             # ordered results, every element once
+    assert [len(a) for a, _ in _toy(7).map(slow, num_parallel_calls=AUTOTUNE)] == list(range(1, 8))
+
+    def boom(a, t):
+        if len(a) == 5:
+            raise ValueError("bad clip")
+        return a, t
+    with pytest.raises(ValueError, match="bad clip"):
+        list(_toy(10).map(boom, num_parallel_calls=3))
+
+
 def test_prefetch_preserves_order_and_propagates_errors():
     assert [len(a) for a, _ in _toy(20).prefetch(2)] == list(range(1, 21))
 
