@@ -266,7 +266,8 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   Im2colLoader<1> av{x, g, K, M, dWo, dHo, dRow};
   Im2colLoader<0> as{x, g, K, M, dWo, dHo, dRow};
   const bool narrow = N <= 32;
-  const int tm = asr_cdiv(M, narrow ? 256 : 64), tn = asr_cdiv(N, narrow ? 32 : 64);
+  const bool tiny = M <= 32;     // a 3x3x3 first-layer filter: 27 rows - a 32-row tile wastes far fewer MFMAs than a 256-row one
+  const int tm = asr_cdiv(M, tiny ? 32 : (narrow ? 256 : 64)), tn = asr_cdiv(N, tiny ? 128 : (narrow ? 32 : 64));
   int splits = 1024 / (tm * tn);
   if (splits < 1) splits = 1;
   const int bk = 32;                         // K partitions are whole K tiles of the kernel used
@@ -275,7 +276,9 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   splits = asr_cdiv(K, k_chunk);
   ASR_CHECK(splits <= 65535, ASR_ERR_SHAPE, "asr_conv2d_bwd_filter: too many K partitions");
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)splits);
-  if (narrow && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  if (tiny && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (tiny) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (narrow && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else if (narrow) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
   else if (vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
