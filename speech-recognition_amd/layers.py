@@ -23,6 +23,47 @@ NG = {"lstm": 4, "gru": 3, "rnn": 1}   # gates in the Keras kernel layout
 NS = {"lstm": 4, "gru": 4, "rnn": 1}   # columns saved per unit by the cell kernels ("slots")
 
 
+class SideStream:
+    """A second HIP stream for work that is off the backward pass's critical path (weight gradients): it is
+    forked from the current stream by an event, so it also becomes a parallel branch of a captured hipGraph,
+    and must be join()ed before the segment ends.  The recurrent sweeps and the decoder chain are latency
+    bound and leave the matrix pipes idle; the weight-gradient GEMMs that nobody downstream waits for run
+    beside them.  Whether that pays is measured per site: deepspeech 18.95 -> 18.38 ms/step (site "ds2", on by
+    default); las_small 17.0 -> 17.6 (encoder weight gradients, "enc") and -> 17.5 (vocabulary weight gradient
+    beside the decoder chain, "dec") - the co-running GEMM waves slow the hand-offs of the persistent sweeps and
+    the short dependent decoder kernels by more than they save, so both are off by default.
+    ASR_SIDE_STREAM = comma list of sites to enable ("enc,dec,ds2"), "1" = all, "0" = none."""
+
+    sites = os.environ.get("ASR_SIDE_STREAM")
+
+    def __init__(self, site="enc", default_on=False):
+        if SideStream.sites is None:
+            on = default_on
+        else:
+            on = SideStream.sites == "1" or site in SideStream.sites.split(",")
+        self.stream = torch.cuda.Stream() if on else None
+        self._busy = False
+
+    def run(self, fn):
+        if self.stream is None:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            fn()
+        self._busy = True
+
+    def join(self):
+        if self.stream is not None and self._busy:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._busy = False
+
+
 def auto_split_k(M, N, K):
     """K partitions for a weight-gradient GEMM (tiny M x N, huge K) so that ~1k workgroups run."""
     # ~2 workgroups per CU: more partitions only add atomic traffic (every partition adds M*N floats)
@@ -36,10 +77,11 @@ def dense_fwd(x2d, W, b, out, relu=False, a_scale=None, a_rpg=0):
 
 
 def dense_bwd(x2d, W, dy2d, gW, gb, dx2d=None, dx_accumulate=False, a_scale=None, a_rpg=0, c_scale=None, c_rpg=0):
-    """gW += x^T dy ; gb += colsum(dy) ; dx (+)= dy W^T."""
+    """gW += x^T dy ; gb += colsum(dy) ; dx (+)= dy W^T.  Any of gW / gb / dx2d may be None (skipped)."""
     Kd = x2d.shape[0]
-    ops.gemm(x2d, dy2d, gW, trans_a=True, accumulate=1, split_k=auto_split_k(gW.shape[0], gW.shape[1], Kd), a_scale=a_scale,
-             a_rpg=a_rpg)
+    if gW is not None:
+        ops.gemm(x2d, dy2d, gW, trans_a=True, accumulate=1, split_k=auto_split_k(gW.shape[0], gW.shape[1], Kd), a_scale=a_scale,
+                 a_rpg=a_rpg)
     if gb is not None:
         ops.colsum(dy2d, gb)
     if dx2d is not None:
@@ -170,11 +212,13 @@ class BiRNN:
             ops.rnn_seq_fwd(buf["seq"])
         return buf["y"]
 
-    def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False):
+    def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False, side=None):
         """dy3d [B,T,2H]; dfinal_h: per direction gradient wrt the final h state ([B,H] or None);
         dc_bufs: per direction [B,H] buffer holding the gradient wrt the final c state on entry and
         the gradient wrt the initial c state on exit (LSTM).  Returns per-direction dh0 buffers.
-        Parameter gradients are accumulated into the store; dx3d (+)= input gradient if not None."""
+        Parameter gradients are accumulated into the store; dx3d (+)= input gradient if not None.
+        side: a SideStream - the weight gradients (which read only this layer's own buffers) then run on it,
+        beside whatever the caller enqueues next; the caller join()s it."""
         B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
         gds = []
         for d, dd in enumerate(buf["dirs"]):
@@ -189,26 +233,35 @@ class BiRNN:
             pws = buf["persist_bwd_ws"]
         ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws)
         x2d = buf["x3d"].reshape(B * T, self.Din)
-        for d, dd in enumerate(buf["dirs"]):
-            g, p = self.store.g, self.store.p
-            nm = self.names[d]
-            ds3 = dd["saved"]
-            ds2 = ds3.view(B * T, -1)
-            mt = dd["mtab"] if buf["drop"] else None
-            cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
-            # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
-            hs = dd["hseq"]
-            for s0, d0, n in slot_cols(rt, H, "rec"):
-                gU = g[nm + "recurrent_kernel"][:, d0:d0 + n]
-                if T > 1:
-                    if dd["reverse"]:
-                        ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1)
-                    else:
-                        ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1)
-                if dd["h0"] is not None:
-                    t0 = T - 1 if dd["reverse"] else 0
-                    ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
-            if dx3d is not None:
-                cell_input_grad(rt, H, ds2, p[nm + "kernel"], dx3d.view(B * T, self.Din), accumulate=(dx_accumulate or d == 1),
-                                c_scale=mt, c_rpg=T)
+        g, p = self.store.g, self.store.p
+
+        def param_grads():      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
+            for d, dd in enumerate(buf["dirs"]):
+                nm = self.names[d]
+                ds3 = dd["saved"]
+                ds2 = ds3.view(B * T, -1)
+                mt = dd["mtab"] if buf["drop"] else None
+                cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
+                # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
+                hs = dd["hseq"]
+                for s0, d0, n in slot_cols(rt, H, "rec"):
+                    gU = g[nm + "recurrent_kernel"][:, d0:d0 + n]
+                    if T > 1:
+                        if dd["reverse"]:
+                            ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                        else:
+                            ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                    if dd["h0"] is not None:
+                        t0 = T - 1 if dd["reverse"] else 0
+                        ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
+
+        if side is not None:
+            side.run(param_grads)
+        else:
+            param_grads()
+        if dx3d is not None:
+            for d, dd in enumerate(buf["dirs"]):
+                mt = dd["mtab"] if buf["drop"] else None
+                cell_input_grad(rt, H, dd["saved"].view(B * T, -1), p[self.names[d] + "kernel"], dx3d.view(B * T, self.Din),
+                                accumulate=(dx_accumulate or d == 1), c_scale=mt, c_rpg=T)
         return [dd["dh0"] for dd in buf["dirs"]]

@@ -17,7 +17,7 @@ import torch
 
 from .. import ops
 from .. import rng as R
-from ..layers import NG, BiRNN, dense_bwd
+from ..layers import NG, BiRNN, SideStream, dense_bwd
 from ..measure import CTCLoss
 from ..params import ParamStore, init_value
 from .las import get_rnn_cls
@@ -61,6 +61,7 @@ class DeepSpeech2(ModelProto):
         self.mask_mode = mask_mode
         self.device, self.init_seed = device, seed
         self._ws = {}
+        self._side = SideStream("ds2", default_on=True)
         self._version, self._packed_version = 0, -1
         self.state = torch.tensor([0, (seed or 0) & 0x7FFFFFFF, 0, 0], dtype=torch.int32, device=device)
 
@@ -248,7 +249,7 @@ class DeepSpeech2(ModelProto):
             ops.bn_bwd(y2, None, da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dy.view(B * T2, 2 * H), g[bn + "gamma"], g[bn + "beta"],
                        ws.bn_ws, relu=False)
             dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * H)
-            dfin = l.backward(lw["rnn"], ws.dy, dfin, ws.dc, dx)
+            dfin = l.backward(lw["rnn"], ws.dy, dfin, ws.dc, dx, side=self._side)   # weight gradients beside the next layer's sweep
             da = dx.view(B * T2, -1)
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
         dy = ws.dx0.view(ws.conv[-1].shape)
@@ -259,6 +260,7 @@ class DeepSpeech2(ModelProto):
             if i > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{i}/kernel"], ws.dconv[i - 1], self.strides[i])
                 dy = ws.dconv[i - 1]
+        self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):

@@ -24,7 +24,7 @@ import torch
 
 from .. import _lib, ops
 from .. import rng as R
-from ..layers import NG, NS, BiRNN, cell_input_grad, cell_param_grads, dense_bwd
+from ..layers import NG, NS, BiRNN, SideStream, cell_input_grad, cell_param_grads, dense_bwd
 from ..measure import SparseCategoricalAccuracy, SparseCategoricalCrossentropy
 from ..params import ParamStore, init_value
 from .model_proto import ModelProto
@@ -116,6 +116,7 @@ class LAS(ModelProto):
         self.listener = Listener(self)
         self.attend_and_speller = AttendAndSpeller(self)
         self._ws = {}
+        self._side, self._side_dec = SideStream("enc"), SideStream("dec")
         self._packed_version = -1
         self._version = 0
         # device state: [0] optimizer iterations, [1] dropout seed (advanced by the trainer each step)
@@ -483,8 +484,9 @@ class LAS(ModelProto):
         # ---- vocabulary projection (las.py:291)
         y_last = ws.dec[-1]["y"].view(U * B, Hd)
         src = ws.yd if rate > 0 else y_last
-        dense_bwd(src, p["attend_and_speller/feedforward/kernel"], ws.logits, g["attend_and_speller/feedforward/kernel"],
-                  g["attend_and_speller/feedforward/bias"], ws.dyd)
+        # the vocabulary weight gradient (16 M outputs, nobody downstream reads it) runs beside the decoder chain
+        self._side_dec.run(lambda: dense_bwd(src, None, ws.logits, g["attend_and_speller/feedforward/kernel"], g["attend_and_speller/feedforward/bias"]))
+        dense_bwd(src, p["attend_and_speller/feedforward/kernel"], ws.logits, None, None, ws.dyd)
         if rate > 0:
             ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
         # ---- decoder steps in reverse (las.py:282-288).  Each cell hands ds (gradient wrt its gate sums,
@@ -591,6 +593,7 @@ class LAS(ModelProto):
                 ops.gemm(st_, dsrc, gW[d * He:(d + 1) * He], trans_a=True, accumulate=1)
                 dst = ws.dfin_h[d] if k == 0 else ws.dc_enc[d]
                 ops.gemm(dsrc, W[d * He:(d + 1) * He], dst, trans_b=True)
+        self._side_dec.join()
 
     def backward_encoder(self, ws, audio):
         p, g = self.store.p, self.store.g
@@ -607,7 +610,7 @@ class LAS(ModelProto):
             dense_bwd(y2, p[f"listener/projection/{i}/kernel"], ws.dz, g[f"listener/projection/{i}/kernel"],
                       g[f"listener/projection/{i}/bias"], ws.dy.view(B * T2, 2 * He))
             dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * He)
-            dh0 = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx)
+            dh0 = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, side=self._side)   # weight gradients beside the next layer's sweep
             dfin = dh0
             da = dx.view(B * T2, -1)
         # ---- convolutions (las.py:183-184)
@@ -621,6 +624,7 @@ class LAS(ModelProto):
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
         ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"])
+        self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):
