@@ -367,6 +367,40 @@ int asr_ctc_greedy(const float* logits, long ld, int B, int T, int V, int blank,
                    int32_t* tokens, int32_t* lengths, float* neg_sum_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Beam search (search.py:83-209 LAS, search.py:254-285 DeepSpeech2).
+ * asr_beam_topk - rows [R, V] of logits -> the k best classes of log_softmax per row in tf.math.top_k order
+ *   (descending, ties -> lowest index): lp [R, k], tok [R, k]  (search.py:128-131).  k <= 32.
+ * asr_beam_select - one step of the LAS beam update for B utterances x `beam` hypotheses (rows b*beam + j),
+ *   reading the `in` state and writing the `out` state (they must not alias):
+ *     candidate (j, m): log_prob = (ended[j] ? 0 : lp[j, m]) + log_ppl[j]            (search.py:136-138)
+ *     length = first EOS + 1 of the extended row, penalty = ((1 + length) / (1 + beta)) ^ alpha in float64
+ *     cast to float32, the `beam` best of log_prob * penalty in stable top_k order     (search.py:159-162)
+ *     hist_out / log_ppl_out = gathered parents (+ the new token)                     (search.py:165-175)
+ *   cur_len = tokens per row so far (BOS included).  At cur_len == 1 the k best classes of row b*beam become the
+ *   beam (search.py:141-153; the caller keeps the beam rows of one utterance identical until then).
+ *   hist [R, ld_hist] int32, log_ppl [R] f32, ended [R] u8 (row holds an EOS), slen [R] int32 (first EOS + 1
+ *   where ended).  next_tok [R] receives the appended tokens, parent [R] the source rows, *final_len the row
+ *   length after this step.  When every row had ended before the step (the reference has left its loop,
+ *   search.py:122-125) the state is forwarded unchanged and *final_len is not touched.
+ *   NOTE the reference does not re-order the decoder states by `parent` (search.py:169 returns them as they
+ *   are); a caller that wants the hypotheses' own states gathers them with `parent`.
+ * asr_ctc_log_softmax - search.py:268-272 on rows [R, V]: out [R, V + 1] = log_softmax of the row with the
+ *   blank class appended last and its old slot masked with -1e9.
+ * asr_ctc_beam_search - HOST function ([TF-sem] tf.nn.ctc_beam_search_decoder, merge_repeated = false, the op
+ *   TensorFlow also runs on the CPU): log_probs host [B, T, C] with the blank as class C - 1, seq_len [B] or
+ *   NULL (= T).  tokens [B, top_paths, T] zero padded, lengths [B, top_paths], log_prob [B, top_paths].
+ *   `threads` host threads share the utterances.
+ * ------------------------------------------------------------------------------------------ */
+int asr_beam_topk(const float* logits, long ld, int R, int V, int k, float* lp, int32_t* tok, void* stream);
+int asr_beam_select(const float* lp, const int32_t* tok, int B, int beam, int cur_len, int ld_hist, int eos, double alpha,
+                    double beta, const int32_t* hist_in, const float* ppl_in, const uint8_t* ended_in, const int32_t* slen_in,
+                    int32_t* hist_out, float* ppl_out, uint8_t* ended_out, int32_t* slen_out, int32_t* next_tok, int32_t* parent,
+                    int32_t* final_len, void* stream);
+int asr_ctc_log_softmax(const float* logits, long ld, long R, int V, int blank, float* out, void* stream);
+int asr_ctc_beam_search(const float* log_probs, int B, int T, int C, const int32_t* seq_len, int beam_width, int top_paths,
+                        int32_t* tokens, int32_t* lengths, float* log_prob, int threads);
+
+/* ------------------------------------------------------------------------------------------
  * Host-side input decoding (no GPU work, thread-safe, re-entrant): what tensorflow-io does for
  * data.py:94-117 and what TFRecord framing needs (data.py:75, run/make_tfrecord.py:47).
  * ------------------------------------------------------------------------------------------ */

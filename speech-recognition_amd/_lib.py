@@ -167,6 +167,11 @@ SIGNATURES = {
     "asr_attn_fused_bwd": (C.c_int, [_P, c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, c_long, C.c_int, _P]),
     "asr_greedy_update": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "asr_ctc_greedy": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "asr_beam_topk": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "asr_beam_select": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P,
+                                  _P, _P, _P, _P]),
+    "asr_ctc_log_softmax": (C.c_int, [_P, c_long, c_long, C.c_int, C.c_int, _P, _P]),
+    "asr_ctc_beam_search": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     "asr_audio_info": (C.c_int, [C.c_char_p, c_long, C.c_int, C.POINTER(AudioInfo)]),
     "asr_audio_decode": (C.c_int, [C.c_char_p, c_long, C.c_int, _P, c_long, C.POINTER(c_long)]),
     "asr_crc32c": (C.c_uint32, [C.c_char_p, c_long, C.c_uint32]),

@@ -41,13 +41,16 @@ class SideStream:
             on = default_on
         else:
             on = SideStream.sites == "1" or site in SideStream.sites.split(",")
-        self.stream = torch.cuda.Stream() if on else None
+        self.on = on
+        self.stream = None                                       # created on first use (a model may be built without a GPU)
         self._busy = False
 
     def run(self, fn):
-        if self.stream is None:
+        if not self.on:
             fn()
             return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)

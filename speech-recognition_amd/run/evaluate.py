@@ -1,6 +1,6 @@
 """`python -m speech_recognition_amd.run.evaluate` - speech_recognition/run/evaluate.py on MI355X: decode a
-dataset greedily with a trained model, report WER / CER, optionally write a (Prediction, Target, WER, CER) TSV.
-Same flags as the reference.  --beam-size > 0 is rejected (beam search is not part of this build); --device
+dataset (greedy search, or beam search with --beam-size) with a trained model, report WER / CER, optionally write
+a (Prediction, Target, WER, CER) TSV.  Same flags as the reference.  --device
 must be GPU; --mixed-precision is accepted and has no effect (fp32 kernels)."""
 import argparse
 import csv
@@ -30,8 +30,6 @@ parser.add_argument("--device", type=str, default="CPU", help="device to train m
 def main(args: argparse.Namespace):
     get_device_strategy(args.device)
     logger = get_logger("inference")
-    if args.beam_size > 0:
-        raise NotImplementedError("beam search is not part of this build: run without --beam-size (greedy search)")
     if args.mixed_precision:
         logger.info("[!] --mixed-precision: this build computes in fp32 on the MFMA; the flag has no effect")
 
@@ -57,7 +55,10 @@ def main(args: argparse.Namespace):
     logger.info("[+] Start Inference")
     outputs = []
     for (audio, target), (n_audio, _) in dataset:
-        tokens = searcher.greedy_search(features(audio, n_audio))[0].cpu().numpy()
+        if args.beam_size > 0:
+            tokens = searcher.beam_search(features(audio, n_audio), args.beam_size)[0][:, 0, :].cpu().numpy()
+        else:
+            tokens = searcher.greedy_search(features(audio, n_audio))[0].cpu().numpy()
         outputs.extend(zip(tokens, target))
     logger.info("[+] Ended Inference")
 

@@ -1,6 +1,6 @@
 """`python -m speech_recognition_amd.run.inference` - speech_recognition/run/inference.py on MI355X: decode
-audio files greedily and write an (AudioPath, DecodedSentence) TSV.  Same flags as the reference; --beam-size > 0
-is rejected (no beam search in this build), --device must be GPU, --mixed-precision has no effect."""
+audio files (greedy search, or beam search with --beam-size) and write an (AudioPath, DecodedSentence) TSV.  Same
+flags as the reference; --device must be GPU, --mixed-precision has no effect."""
 import argparse
 import csv
 import glob
@@ -31,8 +31,6 @@ parser.add_argument("--device", type=str, default="CPU", help="device to train m
 def main(args: argparse.Namespace):
     get_device_strategy(args.device)
     logger = get_logger("inference")
-    if args.beam_size > 0:
-        raise NotImplementedError("beam search is not part of this build: run without --beam-size (greedy search)")
     if args.mixed_precision:
         logger.info("[!] --mixed-precision: this build computes in fp32 on the MFMA; the flag has no effect")
 
@@ -57,7 +55,10 @@ def main(args: argparse.Namespace):
     logger.info("Start Inference")
     outputs = []
     for (audio, _), (n_audio, _) in dataset:
-        outputs.extend(searcher.greedy_search(features(audio, n_audio))[0].cpu().numpy())
+        if args.beam_size > 0:
+            outputs.extend(searcher.beam_search(features(audio, n_audio), args.beam_size)[0][:, 0, :].cpu().numpy())
+        else:
+            outputs.extend(searcher.greedy_search(features(audio, n_audio))[0].cpu().numpy())
     outputs = [tokenizer.detokenize(strip_tokens(row, bos_id, eos_id)) for row in outputs]
     logger.info("Ended Inference, Start to save...")
 

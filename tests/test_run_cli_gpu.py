@@ -38,8 +38,10 @@ def test_evaluate(tmp_path, model, mixed_precision, use_tfrecord):
         assert np.isfinite(float(row[2])) and np.isfinite(float(row[3]))
     if not use_tfrecord:
         assert rows[1][1] != ""                                  # the target sentence survives tokenise -> detokenise
-    with pytest.raises(NotImplementedError):
-        main(parser.parse_args(args + ["--beam-size", "2"]))
+    # --beam-size (run/evaluate.py:97-99): the best hypothesis of the beam is scored instead of the greedy one
+    assert main(parser.parse_args(args + ["--beam-size", "2"])) is None
+    rows = list(csv.reader(open(out), delimiter="\t"))
+    assert len(rows) == 3 and all(np.isfinite(float(r[2])) for r in rows[1:])
 
 
 @pytest.mark.parametrize("model", MODELS)
@@ -50,6 +52,9 @@ def test_inference(tmp_path, model):
     args = ["--data-config", LIBRI, "--model-config", model[0], "--audio-files", audio, "--model-path", model[1], "--output-path", str(out),
             "--sp-model-path", SP_MODEL, "--batch-size", "4", "--device", "GPU"]
     assert main(parser.parse_args(args)) is None
+    rows = list(csv.reader(open(out), delimiter="\t"))
+    assert rows[0] == ["AudioPath", "DecodedSentence"] and len(rows) == 2 and rows[1][0] == audio
+    assert main(parser.parse_args(args + ["--beam-size", "3"])) is None
     rows = list(csv.reader(open(out), delimiter="\t"))
     assert rows[0] == ["AudioPath", "DecodedSentence"] and len(rows) == 2 and rows[1][0] == audio
     with pytest.raises(SystemExit):

@@ -134,8 +134,110 @@ def test_ds2_greedy_search_matches_oracle(mask_mode):
     assert torch.equal(best.cpu().long(), ref_best)              # the frame-level CTC alignment
     assert tok.cpu().numpy().tolist() == ref_tok.tolist()
     assert_close(prob, ref_prob, 5e-4, "sequence probability")
-    with pytest.raises(NotImplementedError):
-        DeepSpeechSearcher(m, 3).beam_search(audio.cuda(), 2)
+
+
+# ---------------------------------------------------------------------------------------------- beam search
+@pytest.mark.parametrize("R,V,k", [(6, 53, 4), (3, 16000, 8), (2, 40, 32)])
+def test_beam_topk_kernel_is_log_softmax_top_k_with_tf_tie_order(R, V, k):
+    from speech_recognition_amd import ops
+    from speech_recognition_amd._lib import check, load
+    g = torch.Generator().manual_seed(R * V + k)
+    logits = torch.randn(R, V, generator=g) * 3
+    logits[0, 5] = logits[0, 9] = logits[0, 2] = 20.0            # three-way tie at the top: index order 2, 5, 9
+    logits[1, 7] = logits[1, 3]                                   # a tie somewhere below
+    d = logits.cuda()
+    lp, tok = torch.empty(R, k).cuda(), torch.empty(R, k, dtype=torch.int32).cuda()
+    check(load().asr_beam_topk(_p(d), V, R, V, k, _p(lp), _p(tok), ops._stream()))
+    lsm = torch.log_softmax(logits.double(), dim=1)
+    for r in range(R):
+        order = sorted(range(V), key=lambda i: (-float(logits[r, i]), i))[:k]
+        assert tok[r].cpu().tolist() == order
+        assert_close(lp[r], lsm[r, order], 1e-5, "top-k log-probabilities")
+    assert tok[0, :3].cpu().tolist() == [2, 5, 9]
+
+
+@pytest.mark.parametrize("rt,beam,max_len", [("lstm", 3, 9), ("gru", 2, 7), ("lstm", 1, 6)])
+def test_las_beam_search_matches_oracle(rt, beam, max_len):
+    from speech_recognition_amd.search import LAS_Searcher
+    cfg = TL.mk_cfg(rt)
+    m, vals = TL.build(cfg)
+    audio, _, _ = TL.inputs(B=3, T=38)
+    bos, eos = 2, 3
+    ref_tok, ref_ppl = OS.beam_las(vals, cfg, audio.double(), max_len, bos, eos, 0, beam)
+    tok, ppl = LAS_Searcher(m, max_len, bos, eos, check_every=2).beam_search(audio.cuda(), beam)
+    assert tuple(tok.shape) == tuple(ref_tok.shape) and tok.dtype == torch.int32
+    assert torch.equal(tok.cpu().long(), ref_tok)
+    assert_close(ppl, ref_ppl, 5e-4, "perplexity")
+
+
+def test_las_beam_search_with_early_eos_matches_oracle():
+    """EOS made likely: hypotheses end at different steps, ended rows spawn equal-scored children (stable top_k
+    ties), the length penalty separates short from long rows and the loop stops once every row holds an EOS."""
+    from speech_recognition_amd.search import LAS_Searcher
+    cfg = TL.mk_cfg("lstm")
+    m, vals = TL.build(cfg)
+    vals = dict(vals)
+    bias = vals["attend_and_speller/feedforward/bias"].clone()
+    bias[3] = 1.5
+    vals["attend_and_speller/feedforward/bias"] = bias
+    m.load_state_dict({k: v.float() for k, v in vals.items()})
+    audio, _, _ = TL.inputs(B=4, T=38)
+    for beam, alpha, beta in ((3, 1, 32), (4, 0.7, 2)):
+        ref_tok, ref_ppl = OS.beam_las(vals, cfg, audio.double(), 14, 2, 3, 0, beam, alpha, beta)
+        tok, ppl = LAS_Searcher(m, 14, 2, 3, check_every=3).beam_search(audio.cuda(), beam, alpha, beta)
+        assert (ref_tok == 3).any()                               # the case is not vacuous
+        assert tuple(tok.shape) == tuple(ref_tok.shape)
+        assert torch.equal(tok.cpu().long(), ref_tok)
+        assert_close(ppl, ref_ppl, 5e-4, "perplexity")
+
+
+def test_beam_one_equals_greedy():
+    """tests/test_search.py:19-25 and 58-64: beam_search(…, 1)[:, 0] equals greedy_search for both models."""
+    from speech_recognition_amd.search import DeepSpeechSearcher, LAS_Searcher
+    cfg = TL.mk_cfg("lstm")
+    m, _ = TL.build(cfg)
+    audio, _, _ = TL.inputs(B=4, T=38)
+    s = LAS_Searcher(m, 10, 2, 3)
+    g_tok, g_ppl = s.greedy_search(audio.cuda())
+    b_tok, b_ppl = s.beam_search(audio.cuda(), 1)
+    assert torch.equal(b_tok[:, 0, :], g_tok)
+    assert_close(b_ppl[:, 0], g_ppl, 1e-4, "perplexity")
+    cfg = TD.mk_cfg("gru")
+    m, _ = TD.build(cfg, "intended")
+    audio, _ = TD.inputs(B=3, T=61)
+    s = DeepSpeechSearcher(m, cfg["blank_index"])
+    g_tok, g_prob = s.greedy_search(audio.cuda())
+    b_tok, b_prob = s.beam_search(audio.cuda(), 1)
+    assert b_tok.shape[1] == 1 and b_prob.shape == (3, 1)
+
+
+@pytest.mark.parametrize("beam", [1, 4, 16])
+def test_ds2_beam_search_matches_oracle(beam):
+    from speech_recognition_amd.search import DeepSpeechSearcher
+    cfg = TD.mk_cfg("gru")
+    m, vals = TD.build(cfg, "intended")
+    audio, _ = TD.inputs(B=3, T=61)
+    ref_tok, ref_prob = OS.beam_ds2(vals, cfg, audio.double(), cfg["blank_index"], beam)
+    tok, prob = DeepSpeechSearcher(m, cfg["blank_index"]).beam_search(audio.cuda(), beam)
+    assert tok.dtype == torch.int32 and tuple(tok.shape) == tuple(ref_tok.shape)
+    assert tok.cpu().numpy().tolist() == ref_tok.tolist()
+    assert_close(prob, torch.from_numpy(ref_prob), 2e-3, "sequence probability")
+
+
+def test_ctc_log_softmax_kernel():
+    from speech_recognition_amd import ops
+    from speech_recognition_amd._lib import check, load
+    g = torch.Generator().manual_seed(3)
+    R, V, blank = 37, 301, 14
+    logits = torch.randn(R, V, generator=g) * 2
+    out = torch.empty(R, V + 1).cuda()
+    check(load().asr_ctc_log_softmax(_p(logits.cuda()), V, R, V, blank, _p(out), ops._stream()))
+    x = torch.cat([logits.double(), logits.double()[:, blank:blank + 1]], dim=1)
+    x[:, blank] += -1e9
+    ref = torch.log_softmax(x, dim=1)
+    keep = [c for c in range(V + 1) if c != blank]
+    assert_close(out[:, keep], ref[:, keep], 1e-5, "log_softmax with the blank last")
+    assert (out[:, blank] < -1e8).all()
 
 
 def test_reference_search_smoke_shapes():
