@@ -52,13 +52,18 @@ typedef struct asr_logmel_cfg {
   int use_delta;                       /* 1: output [..., 3] (x, delta, delta-delta); 0: [..., 1] */
   int sa_enable, sa_F, sa_mF, sa_T, sa_mT; /* SpecAugment; time warp (W) is not supported     */
   float sa_p;
+  int feature_type;                    /* data_config.py:77-101: 0 "log-mel-spectrogram" (data.py:145-189), 1 "spectrogram"
+                                          (data.py:122-142: |STFT|, fft_length/2+1 features, the mel fields are unused),
+                                          2 "mfcc" (data.py:192-241: DCT-II of the log-mel, first num_mfcc coefficients)  */
+  int num_mfcc;                        /* feature_type 2 only, <= num_mel_bins                                      */
 } asr_logmel_cfg;
 
 /* sizes (in elements) of the three constant tables the kernel reads */
 int asr_logmel_table_sizes(const asr_logmel_cfg* cfg, long* n_twiddle_f32, long* n_melw_f32, long* n_melrange_i32);
 /* fills HOST buffers (computed in double, rounded to f32); the caller uploads them once */
 int asr_logmel_build_tables(const asr_logmel_cfg* cfg, float* twiddle, float* melw, int32_t* melrange);
-/* audio [B, n_max] f32 (device), n_samples [B] int32 (device) -> out [B, T_out, mel, C] f32.
+/* audio [B, n_max] f32 (device), n_samples [B] int32 (device) -> out [B, T_out, v, C] f32 with v = num_mel_bins,
+ * fft_length/2+1 or num_mfcc by feature_type (SpecAugment masks act on these v features, data.py:282-301).
  * Frames t >= frames(n_samples[b]) are written as exact 0.0.  seed may be NULL when !sa_enable. */
 int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio, const int32_t* n_samples, int B, int n_max,
                         const float* twiddle, const float* melw, const int32_t* melrange, const uint32_t* seed,

@@ -1,7 +1,9 @@
 """Oracle (TEST INFRASTRUCTURE): audio front end of the training path, numpy float64.
 
 Follows /root/reference/speech_recognition/data.py:
+  make_spectrogram          data.py:122-142   (tf.signal.stft, tf.abs)
   make_log_mel_spectrogram  data.py:145-189   (tf.signal.stft / linear_to_mel_weight_matrix [TF-sem])
+  make_mfcc                 data.py:192-241   (+ tf.signal.mfccs_from_log_mel_spectrograms [TF-sem])
   spec_augment              data.py:244-307   (time warp data.py:275-280 not restated: W is null in
                                                every shipped data config)
   delta_accelerate          data.py:310-328
@@ -61,6 +63,36 @@ def log_mel_spectrogram(audio, sample_rate, frame_length, frame_step, fft_length
     return np.log(power @ mel + epsilon)[:, :, None]
 
 
+def stft_magnitude(audio, frame_length, frame_step, fft_length=None):
+    """[TF-sem] tf.abs(tf.signal.stft(audio, frame_length, frame_step, fft_length)): periodic Hann window, frames
+    without end padding, rfft of length fft_length (default: the smallest power of two >= frame_length; a frame
+    longer than fft_length is cropped by the rfft)."""
+    if fft_length is None:
+        fft_length = 1 << max(int(frame_length) - 1, 0).bit_length()
+    audio = np.asarray(audio, dtype=np.float64)
+    T = num_frames(audio.shape[0], frame_length, frame_step)
+    idx = np.arange(T)[:, None] * frame_step + np.arange(frame_length)[None, :]
+    frames = audio[idx] * hann_periodic(frame_length)[None, :]
+    return np.abs(np.fft.rfft(frames, n=fft_length, axis=1))
+
+
+def spectrogram(audio, frame_length, frame_step, fft_length=None):
+    """data.py:134-137: [T, fft_length // 2 + 1, 1]."""
+    return stft_magnitude(audio, frame_length, frame_step, fft_length)[:, :, None]
+
+
+def mfcc(audio, sample_rate, frame_length, frame_step, fft_length, num_mel_bins=80, num_mfcc=40, lower_edge_hertz=80.0,
+         upper_edge_hertz=7600.0, epsilon=1e-12):
+    """data.py:218-234: log-mel, then [TF-sem] tf.signal.mfccs_from_log_mel_spectrograms =
+    dct(type 2, norm None: X_k = 2 sum_n x_n cos(pi k (2n + 1) / (2N))) * rsqrt(2N), first num_mfcc coefficients."""
+    lm = log_mel_spectrogram(audio, sample_rate, frame_length, frame_step, fft_length, num_mel_bins, lower_edge_hertz,
+                             upper_edge_hertz, epsilon)[:, :, 0]
+    N = num_mel_bins
+    n, k = np.arange(N)[:, None], np.arange(N)[None, :]
+    dct2 = lm @ (2.0 * np.cos(np.pi * k * (2 * n + 1) / (2.0 * N)))
+    return (dct2 / np.sqrt(2.0 * N))[:, :num_mfcc, None]
+
+
 def spec_augment_params(seed, clip, num_time, v, F, m_F, T, p, m_T):
     """Draws of data.py:282-301 with the build's stateless RNG.  Returns
     ([(f0, f), ...], [(t0, t), ...]); zeroed ranges are [f0, f0+f) and [t0, t0+t)."""
@@ -112,13 +144,22 @@ def batch_features(audio, n_samples, cfg, seed=0, spec_aug=None, use_delta=True,
     Ts = [num_frames(int(n), cfg["frame_length"], cfg["frame_step"]) for n in n_samples]
     T_out = T_out or max(Ts)
     C = 3 if use_delta else 1
-    out = np.zeros((B, T_out, cfg["num_mel_bins"], C), dtype=np.float64)
+    ftype = cfg.get("feature_type", "log-mel-spectrogram")            # data_config.py:77-101
+    v = {"log-mel-spectrogram": cfg.get("num_mel_bins"), "spectrogram": cfg["fft_length"] // 2 + 1, "mfcc": cfg.get("num_mfcc")}[ftype]
+    out = np.zeros((B, T_out, v, C), dtype=np.float64)
     for b in range(B):
-        x = log_mel_spectrogram(audio[b, : int(n_samples[b])], cfg["sample_rate"], cfg["frame_length"],
-                                cfg["frame_step"], cfg["fft_length"], cfg["num_mel_bins"],
-                                cfg["lower_edge_hertz"], cfg["upper_edge_hertz"])
+        clip = audio[b, : int(n_samples[b])]
+        if ftype == "spectrogram":
+            x = spectrogram(clip, cfg["frame_length"], cfg["frame_step"], cfg["fft_length"])
+        elif ftype == "mfcc":
+            x = mfcc(clip, cfg["sample_rate"], cfg["frame_length"], cfg["frame_step"], cfg["fft_length"], cfg["num_mel_bins"],
+                     cfg["num_mfcc"], cfg["lower_edge_hertz"], cfg["upper_edge_hertz"])
+        else:
+            x = log_mel_spectrogram(clip, cfg["sample_rate"], cfg["frame_length"],
+                                    cfg["frame_step"], cfg["fft_length"], cfg["num_mel_bins"],
+                                    cfg["lower_edge_hertz"], cfg["upper_edge_hertz"])
         if spec_aug:
-            fr, tm = spec_augment_params(seed, b, Ts[b], cfg["num_mel_bins"], spec_aug.get("F"), spec_aug.get("m_F"),
+            fr, tm = spec_augment_params(seed, b, Ts[b], v, spec_aug.get("F"), spec_aug.get("m_F"),
                                          spec_aug.get("T"), spec_aug.get("p"), spec_aug.get("m_T"))
             x = spec_augment(x, fr, tm)
         if use_delta:

@@ -20,7 +20,8 @@ class LogmelCfg(C.Structure):
     _fields_ = [("sample_rate", C.c_int), ("frame_length", C.c_int), ("frame_step", C.c_int), ("fft_length", C.c_int),
                 ("num_mel_bins", C.c_int), ("lower_edge_hertz", C.c_float), ("upper_edge_hertz", C.c_float),
                 ("epsilon", C.c_float), ("use_delta", C.c_int), ("sa_enable", C.c_int), ("sa_F", C.c_int),
-                ("sa_mF", C.c_int), ("sa_T", C.c_int), ("sa_mT", C.c_int), ("sa_p", C.c_float)]
+                ("sa_mF", C.c_int), ("sa_T", C.c_int), ("sa_mT", C.c_int), ("sa_p", C.c_float),
+                ("feature_type", C.c_int), ("num_mfcc", C.c_int)]
 
 
 class GemmDesc(C.Structure):

@@ -68,27 +68,27 @@ class DataConfig:
 
     @property
     def audio_feature_fn(self):
-        """data_config.py:77-101.  Only the log-mel front end is on the training hot path
-        (libri/kspon/clovacall configs all select it); the others raise."""
-        from ..data import make_log_mel_spectrogram
+        """data_config.py:77-101: the per-clip feature function of this config (all three types run the fused kernel)."""
+        from ..data import make_log_mel_spectrogram, make_mfcc, make_spectrogram
+        if self.audio_feature_type == "spectrogram":
+            return make_spectrogram(self.frame_length, self.frame_step, self.fft_length)
         if self.audio_feature_type == "log-mel-spectrogram":
             return make_log_mel_spectrogram(self.sample_rate, self.frame_length, self.frame_step, self.fft_length,
                                             self.num_mel_bins, self.lower_edge_hertz, self.upper_edge_hertz)
-        raise NotImplementedError(f"audio_feature_type {self.audio_feature_type!r} is outside the MI355X hot path "
-                                  "(no shipped data config selects it)")
+        if self.audio_feature_type == "mfcc":
+            return make_mfcc(self.sample_rate, self.frame_length, self.frame_step, self.fft_length, self.num_mel_bins,
+                             self.num_mfcc, self.lower_edge_hertz, self.upper_edge_hertz)
 
     def logmel_plan(self, training: bool, device="cuda"):
-        """The fused GPU front end (log-mel + SpecAugment when training + delta) for this config."""
+        """The fused GPU front end (features of audio_feature_type + SpecAugment when training + delta) for this config."""
         from .. import ops
-        if self.audio_feature_type != "log-mel-spectrogram":
-            raise NotImplementedError(f"audio_feature_type {self.audio_feature_type!r} has no GPU front end")
         sa = None
         if training and self.spec_augment.enable:
             sa = dict(enable=True, W=self.spec_augment.W, F=self.spec_augment.F, m_F=self.spec_augment.m_F, T=self.spec_augment.T,
                       p=self.spec_augment.p, m_T=self.spec_augment.m_T)
-        return ops.LogmelPlan(self.sample_rate, self.frame_length, self.frame_step, self.fft_length, self.num_mel_bins,
-                              self.lower_edge_hertz, self.upper_edge_hertz, use_delta=self.use_delta_accelerate, spec_augment=sa,
-                              device=device)
+        return ops.LogmelPlan(self.sample_rate, self.frame_length, self.frame_step, self.fft_length, self.num_mel_bins or 0,
+                              self.lower_edge_hertz or 0.0, self.upper_edge_hertz or 0.0, use_delta=self.use_delta_accelerate,
+                              spec_augment=sa, device=device, feature_type=self.audio_feature_type, num_mfcc=self.num_mfcc)
 
     @classmethod
     def from_yaml(cls, file_path) -> "DataConfig":

@@ -1,6 +1,9 @@
 // Fused audio front end for gfx950: framing + Hann window + DFT (f32 MFMA) + |.|^2 + mel filterbank
 // + log + SpecAugment masks + delta / delta-delta + zero padding, one pass over the audio.
 // Replaces data.py:169-187, 282-301, 319-324 and the padded_batch of run/train.py:189-197.
+// The same kernel serves the other two feature types of data_config.py:77-101: "spectrogram" (data.py:122-142:
+// |STFT|, the mel stage is replaced by a square root) and "mfcc" (data.py:192-241: log-mel, then the DCT-II of
+// tf.signal.mfccs_from_log_mel_spectrograms as a small table product, first num_mfcc coefficients).
 //
 // One workgroup = one clip x 16*MT consecutive frames (MT = 4 unless the frame parameters need more LDS
 // than a CU has; all but 2 are written, 2 are halo frames for the two causal differences).  HBM traffic is the algorithmic minimum: every sample is read once per tile
@@ -28,6 +31,8 @@ struct FeArgs {
   int L, step, bins, nmel, C;
   int KS, NBT, pad, seg_len, seg_floats, PLD;
   int sym, KS2;                 // sym: fft_length == frame_length (even): cos/sin symmetry folds the frame, KS2 = DFT k-steps
+  int mode, nf, lmw;            // feature type (0 log-mel, 1 spectrogram, 2 mfcc), features per frame, row width of Lm
+  const float* dct;             // mfcc: [nmel][nf] DCT-II table
   float eps;
   int sa_enable, sa_F, sa_mF, sa_T, sa_mT;
   float sa_p;
@@ -39,8 +44,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* seg = smem;                         // padded sample segment
   float* P = seg + a.seg_floats;             // [FE_FR][PLD] power spectrum
-  float* Lm = P + FE_FR * a.PLD;             // [FE_FR][nmel] masked log-mel
-  int* bands = reinterpret_cast<int*>(Lm + FE_FR * a.nmel);  // [4][FE_MAXBAND]: f0, f, t0, t
+  float* Lm = P + FE_FR * a.PLD;             // [FE_FR][lmw] masked features (mfcc: the unmasked log-mel)
+  float* Fm = Lm + FE_FR * a.lmw;            // mfcc only: [FE_FR][nf] masked cepstral coefficients
+  int* bands = reinterpret_cast<int*>(Fm + (a.mode == 2 ? FE_FR * a.nf : 0));  // [4][FE_MAXBAND]: f0, f, t0, t
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
       if (a.sa_F > 0 && a.sa_mF > 0) {
         for (int i = 0; i < a.sa_mF; ++i) {
           const int f = asr_uniform_int(key, (uint32_t)(b * 64 + 2 * i), a.sa_F);
-          const int f0 = asr_uniform_int(key, (uint32_t)(b * 64 + 2 * i + 1), a.nmel - f);
+          const int f0 = asr_uniform_int(key, (uint32_t)(b * 64 + 2 * i + 1), a.nf - f);
           bands[i] = f0; bands[FE_MAXBAND + i] = f;
         }
       }
@@ -135,31 +141,62 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
   __syncthreads();
 
   // c. mel filterbank (triangles are sparse: only bins melrange[m]..melrange[nmel+m]) + log + masks
-  for (int idx = tid; idx < FE_FR * a.nmel; idx += 256) {
-    const int frame = idx / a.nmel, m = idx - frame * a.nmel;
+  //    (spectrogram: magnitude instead; mfcc: unmasked log-mel here, DCT + masks in c2)
+  const int ncol = a.mode == 1 ? a.nf : a.nmel;
+  for (int idx = tid; idx < FE_FR * ncol; idx += 256) {
+    const int frame = idx / ncol, m = idx - frame * ncol;
     const int t = t0 + frame;
     float v = 0.f;
     if (t >= 0 && t < T_b) {
-      const int lo = a.melrange[m], hi = a.melrange[a.nmel + m];
-      float s = 0.f;
-      for (int bin = lo; bin <= hi; ++bin) s = fmaf(P[frame * a.PLD + bin], a.melw[bin * a.nmel + m], s);
-      // f32 add like tf.math.log(mel + eps), then a correctly rounded log (the reference's silence
-      // fixture pins log(1e-12f) to the last bit; the fast f32 log is 1 ulp off there)
-      const float se = s + a.eps;
-      v = (float)log((double)se);
-      bool zero = false;
-      for (int i = 0; i < a.sa_mF && i < FE_MAXBAND; ++i)
-        zero |= (m >= bands[i] && m < bands[i] + bands[FE_MAXBAND + i]);
-      for (int j = 0; j < a.sa_mT && j < FE_MAXBAND; ++j)
-        zero |= (t >= bands[2 * FE_MAXBAND + j] && t < bands[2 * FE_MAXBAND + j] + bands[3 * FE_MAXBAND + j]);
-      if (a.sa_enable && zero) v = 0.f;
+      if (a.mode == 1) {
+        v = sqrtf(P[frame * a.PLD + m]);                         // tf.abs(stft)
+      } else {
+        const int lo = a.melrange[m], hi = a.melrange[a.nmel + m];
+        float s = 0.f;
+        for (int bin = lo; bin <= hi; ++bin) s = fmaf(P[frame * a.PLD + bin], a.melw[bin * a.nmel + m], s);
+        // f32 add like tf.math.log(mel + eps), then a correctly rounded log (the reference's silence
+        // fixture pins log(1e-12f) to the last bit; the fast f32 log is 1 ulp off there)
+        const float se = s + a.eps;
+        v = (float)log((double)se);
+      }
+      if (a.mode != 2) {
+        bool zero = false;
+        for (int i = 0; i < a.sa_mF && i < FE_MAXBAND; ++i)
+          zero |= (m >= bands[i] && m < bands[i] + bands[FE_MAXBAND + i]);
+        for (int j = 0; j < a.sa_mT && j < FE_MAXBAND; ++j)
+          zero |= (t >= bands[2 * FE_MAXBAND + j] && t < bands[2 * FE_MAXBAND + j] + bands[3 * FE_MAXBAND + j]);
+        if (a.sa_enable && zero) v = 0.f;
+      }
     }
-    Lm[idx] = v;
+    Lm[frame * a.lmw + m] = v;
   }
   __syncthreads();
+  const float* feat = Lm;
+  int fw = a.lmw;
+  if (a.mode == 2) {
+    // c2. mfcc[k] = sum_m logmel[m] * 2 cos(pi k (2m + 1) / (2 nmel)) / sqrt(2 nmel)   (data.py:233-234)
+    for (int idx = tid; idx < FE_FR * a.nf; idx += 256) {
+      const int frame = idx / a.nf, k = idx - frame * a.nf;
+      const int t = t0 + frame;
+      float v = 0.f;
+      if (t >= 0 && t < T_b) {
+        for (int m = 0; m < a.nmel; ++m) v = fmaf(Lm[frame * a.lmw + m], a.dct[m * a.nf + k], v);
+        bool zero = false;
+        for (int i = 0; i < a.sa_mF && i < FE_MAXBAND; ++i)
+          zero |= (k >= bands[i] && k < bands[i] + bands[FE_MAXBAND + i]);
+        for (int j = 0; j < a.sa_mT && j < FE_MAXBAND; ++j)
+          zero |= (t >= bands[2 * FE_MAXBAND + j] && t < bands[2 * FE_MAXBAND + j] + bands[3 * FE_MAXBAND + j]);
+        if (a.sa_enable && zero) v = 0.f;
+      }
+      Fm[idx] = v;
+    }
+    __syncthreads();
+    feat = Fm;
+    fw = a.nf;
+  }
 
   // d. delta / delta-delta (same rounding order as data.py:319-321) and coalesced store
-  const int per_frame = a.nmel * a.C;
+  const int per_frame = a.nf * a.C;
   for (int idx = tid; idx < (FE_FR - 2) * per_frame; idx += 256) {
     const int fo = idx / per_frame + 2, rem = idx % per_frame;
     const int m = rem / a.C, c = rem - m * a.C;
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
     if (t >= a.T_out) continue;
     float v = 0.f;
     if (t < T_b) {
-      const float x0 = Lm[fo * a.nmel + m], x1 = Lm[(fo - 1) * a.nmel + m], x2 = Lm[(fo - 2) * a.nmel + m];
+      const float x0 = feat[fo * fw + m], x1 = feat[(fo - 1) * fw + m], x2 = feat[(fo - 2) * fw + m];
       const float d0 = x0 - x1, d1 = x1 - x2;
       v = c == 0 ? x0 : (c == 1 ? d0 : d0 - d1);
     }
@@ -177,10 +214,18 @@ __global__ __launch_bounds__(256) void logmel_kernel(FeArgs a) {
 
 // ------------------------------------------------------------------------------------------ host
 static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a, int FE_FR = FE_FR_MAX) {
-  ASR_CHECK(c->frame_length > 0 && c->frame_step > 0 && c->fft_length > 0 && c->num_mel_bins > 0,
-            ASR_ERR_SHAPE, "logmel: need frame_length>0, frame_step>0, fft_length>0, num_mel_bins>0");
+  ASR_CHECK(c->frame_length > 0 && c->frame_step > 0 && c->fft_length > 0, ASR_ERR_SHAPE,
+            "logmel: need frame_length>0, frame_step>0, fft_length>0");
+  ASR_CHECK(c->feature_type >= 0 && c->feature_type <= 2, ASR_ERR_ARG, "logmel: feature_type %d (0 log-mel, 1 spectrogram, 2 mfcc)", c->feature_type);
+  ASR_CHECK(c->feature_type == 1 || c->num_mel_bins > 0, ASR_ERR_SHAPE, "logmel: need num_mel_bins>0");
+  ASR_CHECK(c->feature_type != 2 || (c->num_mfcc > 0 && c->num_mfcc <= c->num_mel_bins), ASR_ERR_SHAPE,
+            "logmel: need 0 < num_mfcc <= num_mel_bins, got %d / %d", c->num_mfcc, c->num_mel_bins);
   ASR_CHECK(c->sa_mF <= FE_MAXBAND && c->sa_mT <= FE_MAXBAND, ASR_ERR_SHAPE, "logmel: m_F/m_T > %d", FE_MAXBAND);
-  a->L = c->frame_length; a->step = c->frame_step; a->bins = c->fft_length / 2 + 1; a->nmel = c->num_mel_bins;
+  a->L = c->frame_length; a->step = c->frame_step; a->bins = c->fft_length / 2 + 1;
+  a->mode = c->feature_type;
+  a->nmel = a->mode == 1 ? 1 : c->num_mel_bins;                 // spectrogram: the mel tables are one dummy column
+  a->nf = a->mode == 0 ? a->nmel : (a->mode == 1 ? a->bins : c->num_mfcc);
+  a->lmw = a->mode == 1 ? a->nf : a->nmel;
   a->C = c->use_delta ? 3 : 1;
   a->KS = asr_cdiv(a->L, 4); a->NBT = asr_cdiv(a->bins, 16);
   a->sym = (c->fft_length == c->frame_length && c->frame_length % 2 == 0) ? 1 : 0;
@@ -196,7 +241,8 @@ static int fe_geometry(const asr_logmel_cfg* c, FeArgs* a, int FE_FR = FE_FR_MAX
   return ASR_OK;
 }
 static size_t fe_smem_bytes(const FeArgs& a, int FE_FR) {
-  return sizeof(float) * ((size_t)a.seg_floats + (size_t)FE_FR * a.PLD + (size_t)FE_FR * a.nmel) + sizeof(int) * 4 * FE_MAXBAND;
+  return sizeof(float) * ((size_t)a.seg_floats + (size_t)FE_FR * a.PLD + (size_t)FE_FR * a.lmw + (a.mode == 2 ? (size_t)FE_FR * a.nf : 0)) +
+         sizeof(int) * 4 * FE_MAXBAND;
 }
 
 extern "C" int asr_logmel_table_sizes(const asr_logmel_cfg* cfg, long* n_tw, long* n_melw, long* n_range) {
@@ -205,7 +251,7 @@ extern "C" int asr_logmel_table_sizes(const asr_logmel_cfg* cfg, long* n_tw, lon
   int rc = fe_geometry(cfg, &a);
   if (rc) return rc;
   *n_tw = (long)a.NBT * 2 * a.KS2 * 64;
-  *n_melw = (long)a.bins * a.nmel;
+  *n_melw = (long)a.bins * a.nmel + (a.mode == 2 ? (long)a.nmel * a.nf : 0);    // mfcc: the DCT table follows the mel matrix
   *n_range = 2L * a.nmel;
   return ASR_OK;
 }
@@ -244,6 +290,18 @@ extern "C" int asr_logmel_build_tables(const asr_logmel_cfg* cfg, float* tw, flo
           }
           tw[((long)(bt * 2 + cs) * a.KS2 + ks) * 64 + lane] = (float)v;
         }
+  if (a.mode == 1) {                                             // spectrogram: no mel stage, one dummy column
+    for (int bin = 0; bin < a.bins; ++bin) melw[bin] = 0.f;
+    range[0] = 0; range[1] = -1;
+    return ASR_OK;
+  }
+  if (a.mode == 2) {
+    // [TF-sem] tf.signal.mfccs_from_log_mel_spectrograms = dct(type 2, unnormalised: 2 sum x cos(pi k (2m+1) / 2N)) * rsqrt(2N)
+    float* dct = melw + (long)a.bins * a.nmel;
+    const double sc = 2.0 / sqrt(2.0 * a.nmel);
+    for (int m = 0; m < a.nmel; ++m)
+      for (int k = 0; k < a.nf; ++k) dct[(long)m * a.nf + k] = (float)(sc * cos(PI * k * (2.0 * m + 1.0) / (2.0 * a.nmel)));
+  }
   // [TF-sem] tf.signal.linear_to_mel_weight_matrix: HTK mel, triangles on the mel axis, DC row zero
   auto hz2mel = [](double f) { return 1127.0 * log1p(f / 700.0); };
   const double nyq = cfg->sample_rate / 2.0;
@@ -299,6 +357,7 @@ extern "C" int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio
   }
   ASR_CHECK(MT >= 1, ASR_ERR_SHAPE, "asr_logmel_features: frame parameters need %zu B of LDS (> 160 KiB)", smem);
   a.audio = audio; a.n_samples = n_samples; a.tw = tw; a.melw = melw; a.melrange = melrange; a.seed = seed; a.out = out;
+  a.dct = melw + (long)a.bins * a.nmel;
   a.B = B; a.n_max = n_max; a.T_out = T_out;
   static bool attr_set = false;
   if (!attr_set) {

@@ -364,18 +364,14 @@ def _lengths(n, B, full, device):
     return _to_device(n, torch.int32)
 
 
-def make_log_mel_spectrogram(sample_rate: int, frame_length: int, frame_step: int, fft_length: int, num_mel_bins: int = 80,
-                             lower_edge_hertz: float = 80.0, upper_edge_hertz: float = 7600.0, epsilon: float = 1e-12):
-    """data.py:145-189.  Returned callable: (audio[, text][, n_samples]) -> log-mel (, text).
-    audio [N] -> [NumFrame, num_mel_bins, 1]; a padded batch [B, N] with n_samples [B] -> [B, NumFrame, mel, 1]
-    (frames past each clip's end are exact zeros, i.e. already padded_batch'ed)."""
+def _feature_fn(plan_kwargs):
+    """Shared body of the three make_* wrappers: build the fused front-end plan on first use, run it."""
     from . import ops
     plan = [None]
 
     def _wrapper(audio, text=None, n_samples=None):
         if plan[0] is None:
-            plan[0] = ops.LogmelPlan(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, lower_edge_hertz,
-                                     upper_edge_hertz, epsilon, use_delta=False)
+            plan[0] = ops.LogmelPlan(use_delta=False, **plan_kwargs)
         x = _to_device(audio)
         single = x.dim() == 1
         if single:
@@ -387,6 +383,34 @@ def make_log_mel_spectrogram(sample_rate: int, frame_length: int, frame_step: in
         return out if text is None else (out, text)
 
     return _wrapper
+
+
+def make_spectrogram(frame_length: int, frame_step: int, fft_length: Optional[int] = None):
+    """data.py:122-142: |STFT|.  audio [N] -> [NumFrame, fft_length // 2 + 1, 1] (a padded batch [B, N] with n_samples
+    likewise).  fft_length None = the smallest power of two enclosing frame_length ([TF-sem] tf.signal.stft)."""
+    if fft_length is None:
+        fft_length = 1 << max(int(frame_length) - 1, 0).bit_length()
+    return _feature_fn(dict(sample_rate=0, frame_length=frame_length, frame_step=frame_step, fft_length=fft_length, num_mel_bins=0,
+                            lower_edge_hertz=0.0, upper_edge_hertz=0.0, feature_type="spectrogram"))
+
+
+def make_log_mel_spectrogram(sample_rate: int, frame_length: int, frame_step: int, fft_length: int, num_mel_bins: int = 80,
+                             lower_edge_hertz: float = 80.0, upper_edge_hertz: float = 7600.0, epsilon: float = 1e-12):
+    """data.py:145-189.  Returned callable: (audio[, text][, n_samples]) -> log-mel (, text).
+    audio [N] -> [NumFrame, num_mel_bins, 1]; a padded batch [B, N] with n_samples [B] -> [B, NumFrame, mel, 1]
+    (frames past each clip's end are exact zeros, i.e. already padded_batch'ed)."""
+    return _feature_fn(dict(sample_rate=sample_rate, frame_length=frame_length, frame_step=frame_step, fft_length=fft_length,
+                            num_mel_bins=num_mel_bins, lower_edge_hertz=lower_edge_hertz, upper_edge_hertz=upper_edge_hertz,
+                            epsilon=epsilon))
+
+
+def make_mfcc(sample_rate: int, frame_length: int, frame_step: int, fft_length: int, num_mel_bins: int = 80, num_mfcc: int = 40,
+              lower_edge_hertz: float = 80.0, upper_edge_hertz: float = 7600.0, epsilon: float = 1e-12):
+    """data.py:192-241: DCT-II of the log-mel spectrogram ([TF-sem] tf.signal.mfccs_from_log_mel_spectrograms), first
+    num_mfcc coefficients.  audio [N] -> [NumFrame, num_mfcc, 1]."""
+    return _feature_fn(dict(sample_rate=sample_rate, frame_length=frame_length, frame_step=frame_step, fft_length=fft_length,
+                            num_mel_bins=num_mel_bins, lower_edge_hertz=lower_edge_hertz, upper_edge_hertz=upper_edge_hertz,
+                            epsilon=epsilon, feature_type="mfcc", num_mfcc=num_mfcc))
 
 
 _sa_calls = [0]

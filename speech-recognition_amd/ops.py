@@ -46,8 +46,17 @@ class LogmelPlan:
     """Constant tables of the fused front-end kernel for one DataConfig (built once, on host in
     float64 inside the library, uploaded once)."""
 
+    FEATURE_TYPES = {"log-mel-spectrogram": 0, "spectrogram": 1, "mfcc": 2}
+
     def __init__(self, sample_rate, frame_length, frame_step, fft_length, num_mel_bins=80, lower_edge_hertz=80.0,
-                 upper_edge_hertz=7600.0, epsilon=1e-12, use_delta=True, spec_augment=None, device="cuda"):
+                 upper_edge_hertz=7600.0, epsilon=1e-12, use_delta=True, spec_augment=None, device="cuda",
+                 feature_type="log-mel-spectrogram", num_mfcc=None):
+        """feature_type (data_config.py:77-101): "log-mel-spectrogram" (data.py:145-189), "spectrogram"
+        (data.py:122-142, the mel arguments are ignored) or "mfcc" (data.py:192-241, first num_mfcc coefficients)."""
+        if feature_type not in self.FEATURE_TYPES:
+            raise ValueError(f"feature_type {feature_type!r}: expected one of {sorted(self.FEATURE_TYPES)}")
+        ft = self.FEATURE_TYPES[feature_type]
+        num_mel_bins = int(num_mel_bins or 0)
         sa = spec_augment or {}
         if sa.get("W"):
             raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
@@ -58,7 +67,7 @@ class LogmelPlan:
                                   upper_edge_hertz, epsilon, 1 if use_delta else 0, 1 if enable else 0,
                                   int(sa.get("F") or 0) if use_f else 0, int(sa.get("m_F") or 0) if use_f else 0,
                                   int(sa.get("T") or 0) if use_t else 0, int(sa.get("m_T") or 0) if use_t else 0,
-                                  float(sa.get("p") or 0.0) if use_t else 0.0)
+                                  float(sa.get("p") or 0.0) if use_t else 0.0, ft, int(num_mfcc or 0))
         n1, n2, n3 = C.c_long(), C.c_long(), C.c_long()
         check(lib().asr_logmel_table_sizes(C.byref(self.cfg), C.byref(n1), C.byref(n2), C.byref(n3)))
         tw = np.empty(n1.value, np.float32)
@@ -66,12 +75,18 @@ class LogmelPlan:
         mr = np.empty(n3.value, np.int32)
         check(lib().asr_logmel_build_tables(C.byref(self.cfg), tw.ctypes.data_as(C.c_void_p), mw.ctypes.data_as(C.c_void_p),
                                             mr.ctypes.data_as(C.c_void_p)))
-        self.melw_host = mw.reshape(fft_length // 2 + 1, num_mel_bins)
+        bins = fft_length // 2 + 1
+        mel_cols = 1 if ft == 1 else num_mel_bins                # spectrogram: the library keeps one dummy mel column
+        self.melw_host = mw[:bins * mel_cols].reshape(bins, mel_cols)
+        # features per frame (the reference's frequency_dim, data_config.py:65-74); `num_mel_bins` keeps naming it for
+        # the callers that size their buffers with it
+        self.num_features = (num_mel_bins, bins, int(num_mfcc or 0))[ft]
+        self.feature_type = feature_type
         self.tw = torch.from_numpy(tw).to(device)
         self.melw = torch.from_numpy(mw).to(device)
         self.melrange = torch.from_numpy(mr).to(device)
         self.channels = 3 if use_delta else 1
-        self.num_mel_bins = num_mel_bins
+        self.num_mel_bins = self.num_features
         self.frame_length, self.frame_step = frame_length, frame_step
 
     def num_frames(self, n_samples: int) -> int:
@@ -141,7 +156,7 @@ def spec_augment_cfg(v, F=None, m_F=None, T=None, p=None, m_T=None):
     """asr_logmel_cfg carrying only the SpecAugment fields (for asr_spec_augment on stored features)."""
     use_f, use_t = all([F, m_F]), all([T, p, m_T])
     return _lib.LogmelCfg(0, 0, 0, 0, int(v), 0.0, 0.0, 0.0, 0, 1 if (use_f or use_t) else 0, int(F) if use_f else 0,
-                          int(m_F) if use_f else 0, int(T) if use_t else 0, int(m_T) if use_t else 0, float(p) if use_t else 0.0)
+                          int(m_F) if use_f else 0, int(T) if use_t else 0, int(m_T) if use_t else 0, float(p) if use_t else 0.0, 0, 0)
 
 
 def spec_augment_(cfg, x, n_frames, seed):

@@ -110,3 +110,76 @@ def test_spec_augment_matches_oracle_and_reference_bounds(sa):
 def test_time_warp_is_rejected():
     with pytest.raises(NotImplementedError):
         _plan(spec_augment=dict(enable=True, W=80, F=27, m_F=1, T=100, p=1.0, m_T=1))
+
+
+# ---------------------------------------------------------------------------------------------- other feature types
+# parameter sets of the reference's tests/test_data.py:60-145 (shape checks there; values against the oracle here)
+@pytest.mark.parametrize("frame_length,frame_step,fft_length", [(1024, 1024, 1024), (128, 64, 256), (128, 80, None), (512, 512, 256)])
+def test_make_spectrogram(frame_length, frame_step, fft_length):
+    from speech_recognition_amd.data import make_spectrogram
+    n = 16000 + 13
+    audio = _audio(1, n, 5)[0]
+    out = make_spectrogram(frame_length, frame_step, fft_length)(audio)
+    fl = fft_length or frame_length
+    assert tuple(out.shape) == ((n - frame_length + frame_step) // frame_step, fl // 2 + 1, 1)      # tests/test_data.py:74-77
+    ref = F.spectrogram(audio.astype(np.float64), frame_length, frame_step, fft_length)
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err.max() < 2e-4 * max(1.0, ref.max()), (err.max(), ref.max())
+
+
+@pytest.mark.parametrize("sample_rate,frame_length,frame_step,fft_length,num_mel_bins,num_mfcc,lower,upper",
+                         [(22050, 1024, 1024, 1024, 80, 40, 10, 10000), (16000, 128, 64, 256, 123, 33, 12, 88),
+                          (32000, 128, 80, 128, 321, 100, 32, 16000), (44100, 512, 512, 256, 333, 333, 333, 3333)])
+def test_make_mfcc(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, num_mfcc, lower, upper):
+    from speech_recognition_amd.data import make_log_mel_spectrogram, make_mfcc
+    n = 16000 + 13
+    audio = _audio(1, n, 6)[0]
+    out = make_mfcc(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, num_mfcc, lower, upper)(audio)
+    T = (n - frame_length + frame_step) // frame_step
+    assert tuple(out.shape) == (T, num_mfcc, 1)                                                       # tests/test_data.py:141-145
+    ref = F.mfcc(audio.astype(np.float64), sample_rate, frame_length, frame_step, fft_length, num_mel_bins, num_mfcc, lower, upper)
+    # the DCT sums num_mel_bins log-mel values of magnitude up to ~28 (log 1e-12 on empty filters): scale the tolerance
+    scale = np.abs(ref).max()
+    assert np.abs(out.cpu().numpy() - ref).max() < 3e-4 * max(1.0, scale)
+    # and the kernel's own log-mel, transformed on the host, gives the same numbers (DCT stage in isolation)
+    lm = make_log_mel_spectrogram(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, lower, upper)(audio)[:, :, 0].cpu().numpy()
+    nn, kk = np.arange(num_mel_bins)[:, None], np.arange(num_mel_bins)[None, :]
+    dct = (lm.astype(np.float64) @ (2.0 * np.cos(np.pi * kk * (2 * nn + 1) / (2.0 * num_mel_bins)))) / np.sqrt(2.0 * num_mel_bins)
+    assert np.abs(out[:, :, 0].cpu().numpy() - dct[:, :num_mfcc]).max() < 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("ftype,extra", [("spectrogram", {}), ("mfcc", dict(num_mfcc=40))])
+def test_feature_types_with_specaugment_delta_and_padding(ftype, extra):
+    """The whole fused path (features -> SpecAugment on the v features -> delta -> zero padding) for the two other types."""
+    B, n = 3, 16000 + 77
+    audio = _audio(B, n, 7)
+    ns = np.array([n, 9000, 320 + 160 * 20], np.int32)
+    cfg = dict(LIBRI, feature_type=ftype, **extra)
+    sa = dict(F=9, m_F=2, T=12, p=0.5, m_T=2)
+    plan = _plan(feature_type=ftype, spec_augment=dict(enable=True, **sa), **extra)
+    seed = torch.tensor([1234], dtype=torch.int32, device="cuda")
+    T_out = plan.num_frames(n) + 3
+    out = plan(gpu(audio), torch.from_numpy(ns).cuda(), T_out, seed)
+    ref = F.batch_features(audio.astype(np.float64), ns, cfg, seed=1234, spec_aug=sa, use_delta=True, T_out=T_out)
+    assert tuple(out.shape) == ref.shape and out.shape[2] == (161 if ftype == "spectrogram" else 40)
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err.max() < 3e-3, err.max()
+    zero_ref = ref[..., 0] == 0.0
+    assert (out[..., 0].cpu().numpy()[zero_ref] == 0.0).all()    # masked bands and padding are exact zeros
+
+
+def test_data_config_feature_types():
+    from speech_recognition_amd.configs import DataConfig
+    base = dict(file_format="wav", sample_rate=16000, frame_length=320, frame_step=160, fft_length=320, max_audio_length=1000,
+                max_token_length=50, use_delta_accelerate=True, spec_augment=dict(enable=False))
+    for ftype, extra, v in (("spectrogram", {}, 161), ("mfcc", dict(num_mel_bins=80, num_mfcc=13, lower_edge_hertz=80.0, upper_edge_hertz=7600.0), 13),
+                            ("log-mel-spectrogram", dict(num_mel_bins=80, lower_edge_hertz=80.0, upper_edge_hertz=7600.0), 80)):
+        dc = DataConfig(audio_feature_type=ftype, **base, **extra)
+        assert dc.frequency_dim == v
+        plan = dc.logmel_plan(training=False)
+        audio = gpu(_audio(2, 4000, 8))
+        out = plan(audio, torch.full((2,), 4000, dtype=torch.int32, device="cuda"), plan.num_frames(4000))
+        assert tuple(out.shape) == (2, 24, v, 3)
+        single = dc.audio_feature_fn(audio[0])
+        assert tuple(single.shape) == (24, v, 1)
+        assert torch.equal(single[:, :, 0], out[0, :, :, 0])
