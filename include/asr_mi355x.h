@@ -50,7 +50,7 @@ typedef struct asr_logmel_cfg {
   int sample_rate, frame_length, frame_step, fft_length, num_mel_bins;
   float lower_edge_hertz, upper_edge_hertz, epsilon;
   int use_delta;                       /* 1: output [..., 3] (x, delta, delta-delta); 0: [..., 1] */
-  int sa_enable, sa_F, sa_mF, sa_T, sa_mT; /* SpecAugment; time warp (W) is not supported     */
+  int sa_enable, sa_F, sa_mF, sa_T, sa_mT; /* SpecAugment masks; the time warp (W) is asr_time_warp */
   float sa_p;
   int feature_type;                    /* data_config.py:77-101: 0 "log-mel-spectrogram" (data.py:145-189), 1 "spectrogram"
                                           (data.py:122-142: |STFT|, fft_length/2+1 features, the mel fields are unused),
@@ -80,6 +80,15 @@ int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio, const int
 int asr_spec_augment(const asr_logmel_cfg* cfg, float* x, const int32_t* n_frames, int B, int T, int C,
                      const uint32_t* seed, void* stream);
 int asr_delta_accelerate(const float* x, const int32_t* n_frames, int B, int T, int v, float* out, void* stream);
+/* asr_time_warp (data.py:275-280, SpecAugment's time warping): per clip tfa.image.sparse_image_warp of the
+ * [T_b, v, C] feature image with ONE control point moved along time, (src, v/2) -> (dst, v/2),
+ * src = W + U{0 .. T_b-2W-1}, dst = src - W + U{0 .. 2W-1} (RNG stream 5, indices 2b and 2b+1),
+ * num_boundary_points = 3 (12 zero-flow points on the image border), polyharmonic spline of order 2,
+ * bilinear resampling.  x [B, T, v, C] -> out [B, T, v, C] (must not alias x); frames t >= n_frames[b]
+ * (NULL = T) and clips with T_b <= 2W (where the reference's draw range is empty) are copied unchanged.
+ * coef: [B, 32] floats of scratch (the spline of each clip). */
+int asr_time_warp(const float* x, const int32_t* n_frames, int B, int T, int v, int C, int W, const uint32_t* seed,
+                  float* coef, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense contraction (tf.matmul / Dense / the batched halves of LSTM, attention and vocab

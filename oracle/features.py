@@ -4,8 +4,8 @@ Follows /root/reference/speech_recognition/data.py:
   make_spectrogram          data.py:122-142   (tf.signal.stft, tf.abs)
   make_log_mel_spectrogram  data.py:145-189   (tf.signal.stft / linear_to_mel_weight_matrix [TF-sem])
   make_mfcc                 data.py:192-241   (+ tf.signal.mfccs_from_log_mel_spectrograms [TF-sem])
-  spec_augment              data.py:244-307   (time warp data.py:275-280 not restated: W is null in
-                                               every shipped data config)
+  spec_augment              data.py:244-307   (time warp data.py:275-280 = tfa.image.sparse_image_warp [TF-sem],
+                                               restated below from tensorflow-addons' published algorithm)
   delta_accelerate          data.py:310-328
 and the zero padding of `padded_batch` in run/train.py:189-197.
 """
@@ -125,6 +125,72 @@ def spec_augment(x, freq, time):
     return x
 
 
+STREAM_TIMEWARP = 5  # RNG stream id of the two time-warp draws (index 2*clip, 2*clip + 1)
+
+
+def time_warp_params(seed, clip, num_time, W):
+    """data.py:276-277: src = uniform((), W, num_time - W), dst = src + uniform((), -W, W) with the build's RNG.
+    None when the first range is empty (the reference raises there; the build leaves the clip unchanged)."""
+    if num_time <= 2 * W or num_time < 2:
+        return None
+    src = W + rng.uniform_int(seed, STREAM_TIMEWARP, 2 * clip, num_time - 2 * W)
+    dst = src - W + rng.uniform_int(seed, STREAM_TIMEWARP, 2 * clip + 1, 2 * W)
+    return src, dst
+
+
+def _phi2(r):
+    """tfa interpolate_spline._phi, order 2, on SQUARED distances: 0.5 r log(max(r, 1e-10))."""
+    return 0.5 * r * np.log(np.maximum(r, 1e-10))
+
+
+def sparse_image_warp(image, src, dst, num_boundary_points=3):
+    """[TF-sem] tfa.image.sparse_image_warp(image [H, W, C], src [n, 2], dst [n, 2] as (y, x), interpolation_order=2,
+    regularization_weight=0): zero-flow control points on the border of a (num_boundary_points + 1)^2 grid are added,
+    a polyharmonic spline through the flows (dst - src) AT THE DESTINATION points is solved
+    ([[phi(D), P], [P^T, 0]] [w; v] = [f; 0], P = [y, x, 1]) and evaluated on every pixel, and
+    tfa.image.dense_image_warp reads image[y - flow_y, x - flow_x] bilinearly (floor clamped to [0, size - 2],
+    weight clamped to [0, 1]).  float64 throughout (TensorFlow: float32)."""
+    image = np.asarray(image, np.float64)
+    H, Wd, _ = image.shape
+    src, dst = np.asarray(src, np.float64).reshape(-1, 2), np.asarray(dst, np.float64).reshape(-1, 2)
+    flows = dst - src
+    k = num_boundary_points - 1
+    ys, xs = np.meshgrid(np.linspace(0, H - 1, k + 2), np.linspace(0, Wd - 1, k + 2), indexing="ij")
+    border = (xs == 0) | (xs == Wd - 1) | (ys == 0) | (ys == H - 1)
+    bpts = np.stack([ys[border], xs[border]], axis=-1).astype(np.float32).astype(np.float64)
+    pts = np.concatenate([dst, bpts], axis=0)
+    f = np.concatenate([flows, np.zeros_like(bpts)], axis=0)
+    n = pts.shape[0]
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    P = np.concatenate([pts, np.ones((n, 1))], axis=1)
+    lhs = np.block([[_phi2(d2), P], [P.T, np.zeros((3, 3))]])
+    rhs = np.concatenate([f, np.zeros((3, 2))], axis=0)
+    wv = np.linalg.solve(lhs, rhs)
+    w, v = wv[:n], wv[n:]
+    gy, gx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(Wd, dtype=np.float64), indexing="ij")
+    q = np.stack([gy.ravel(), gx.ravel()], axis=1)
+    qd2 = ((q[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    flow = _phi2(qd2) @ w + np.concatenate([q, np.ones((q.shape[0], 1))], axis=1) @ v
+    query = q - flow
+    fl, al = [], []
+    for dim, size in ((0, H), (1, Wd)):
+        fdim = np.minimum(np.maximum(0.0, np.floor(query[:, dim])), size - 2)
+        fl.append(fdim.astype(np.int64))
+        al.append(np.clip(query[:, dim] - fdim, 0.0, 1.0)[:, None])
+    tl, tr = image[fl[0], fl[1]], image[fl[0], fl[1] + 1]
+    bl, br = image[fl[0] + 1, fl[1]], image[fl[0] + 1, fl[1] + 1]
+    top = al[1] * (tr - tl) + tl
+    bot = al[1] * (br - bl) + bl
+    return (al[0] * (bot - top) + top).reshape(image.shape), flow.reshape(H, Wd, 2)
+
+
+def time_warp(x, src_time, dst_time):
+    """data.py:278-280: one control point (src_time, v // 2) -> (dst_time, v // 2), num_boundary_points=3."""
+    v = x.shape[1]
+    out, _ = sparse_image_warp(x, [[src_time, v // 2]], [[dst_time, v // 2]], 3)
+    return out
+
+
 def delta_accelerate(x):
     """data.py:319-324: delta[t] = x[t]-x[t-1] with x[-1]=0; deltas likewise on delta; concat."""
     z = np.zeros_like(x[:1])
@@ -158,6 +224,10 @@ def batch_features(audio, n_samples, cfg, seed=0, spec_aug=None, use_delta=True,
             x = log_mel_spectrogram(clip, cfg["sample_rate"], cfg["frame_length"],
                                     cfg["frame_step"], cfg["fft_length"], cfg["num_mel_bins"],
                                     cfg["lower_edge_hertz"], cfg["upper_edge_hertz"])
+        if spec_aug and spec_aug.get("W"):                            # data.py:275-280, before the masks
+            tw = time_warp_params(seed, b, Ts[b], spec_aug["W"])
+            if tw is not None:
+                x = time_warp(x, tw[0], tw[1])
         if spec_aug:
             fr, tm = spec_augment_params(seed, b, Ts[b], v, spec_aug.get("F"), spec_aug.get("m_F"),
                                          spec_aug.get("T"), spec_aug.get("p"), spec_aug.get("m_T"))

@@ -117,6 +117,7 @@ SIGNATURES = {
     "asr_logmel_features": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
     "asr_spec_augment": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "asr_delta_accelerate": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "asr_time_warp": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "asr_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),

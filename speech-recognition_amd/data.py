@@ -418,13 +418,11 @@ _sa_calls = [0]
 
 def spec_augment(v: int, W: Optional[int] = None, F: Optional[int] = None, m_F: Optional[int] = None, T: Optional[int] = None,
                  p: Optional[float] = None, m_T: Optional[int] = None):
-    """data.py:244-307 (frequency and time masking; W, the time warp, is unsupported as in the fused path).
+    """data.py:244-307: time warping (W), frequency masking (F, m_F) and time masking (T, p, m_T), in that order.
     Returned callable: (features[, text][, n_frames][, seed]) -> masked features (a new tensor).
     features [T, v, C] or a padded batch [B, T, v, C] with n_frames [B].  seed: int; by default a new one
     per call drawn from Python's `random` (so utils.set_random_seed makes runs repeatable)."""
     from . import ops
-    if W:
-        raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
     cfg = ops.spec_augment_cfg(v, F, m_F, T, p, m_T)
 
     def _wrapper(audio, text=None, n_frames=None, seed=None):
@@ -438,6 +436,8 @@ def spec_augment(v: int, W: Optional[int] = None, F: Optional[int] = None, m_F: 
         _sa_calls[0] += 1
         seed_dev = torch.tensor([int(seed) & 0x7FFFFFFF], dtype=torch.int32, device=x.device)
         nf = _lengths(n_frames, B, Tn, x.device)
+        if W:                                                    # data.py:269, 275-280
+            x = ops.time_warp(x, nf, W, seed_dev)
         ops.spec_augment_(cfg, x, nf, seed_dev)
         out = x[0] if single else x
         return out if text is None else (out, text)

@@ -58,9 +58,14 @@ class LogmelPlan:
         ft = self.FEATURE_TYPES[feature_type]
         num_mel_bins = int(num_mel_bins or 0)
         sa = spec_augment or {}
-        if sa.get("W"):
-            raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
         enable = bool(spec_augment) and bool(sa.get("enable", True))
+        # SpecAugment's time warp (data.py:275-280) resamples whole clips along time, so it cannot live in the fused
+        # kernel's per-tile pass: the kernel then emits plain features and a StoredFeaturePlan does warp -> masks -> delta
+        self._tail = None
+        if enable and sa.get("W"):
+            self._tail = StoredFeaturePlan(0, use_delta, spec_augment)       # v is filled in below
+            self._final_channels = 3 if use_delta else 1
+            enable, use_delta = False, False
         use_f = bool(sa.get("F")) and bool(sa.get("m_F"))
         use_t = bool(sa.get("T")) and bool(sa.get("p")) and bool(sa.get("m_T"))
         self.cfg = _lib.LogmelCfg(sample_rate, frame_length, frame_step, fft_length, num_mel_bins, lower_edge_hertz,
@@ -88,6 +93,10 @@ class LogmelPlan:
         self.channels = 3 if use_delta else 1
         self.num_mel_bins = self.num_features
         self.frame_length, self.frame_step = frame_length, frame_step
+        if self._tail is not None:
+            self._tail.set_num_features(self.num_features)
+            self.channels = self._final_channels
+            self._raw = {}
 
     def num_frames(self, n_samples: int) -> int:
         return 0 if n_samples < self.frame_length else 1 + (n_samples - self.frame_length) // self.frame_step
@@ -102,8 +111,20 @@ class LogmelPlan:
         if out is None:
             out = torch.empty(B, T_out, self.num_mel_bins, self.channels, device=audio.device, dtype=torch.float32)
         assert audio.is_contiguous() and out.is_contiguous()
+        dst = out
+        if self._tail is not None:
+            key = (B, T_out)
+            if key not in self._raw:
+                self._raw[key] = torch.empty(B, T_out, self.num_mel_bins, 1, device=audio.device, dtype=torch.float32)
+            dst = self._raw[key]
         check(lib().asr_logmel_features(C.byref(self.cfg), _p(audio), _p(n_samples), B, n_max, _p(self.tw), _p(self.melw),
-                                        _p(self.melrange), _p(seed), _p(out), T_out, _stream()))
+                                        _p(self.melrange), _p(seed), _p(dst), T_out, _stream()))
+        if self._tail is not None:
+            # frames per clip, on the device (tf.signal.frame without end padding)
+            n_frames = torch.where(n_samples >= self.frame_length,
+                                   torch.div(n_samples - self.frame_length, self.frame_step, rounding_mode="floor") + 1,
+                                   torch.zeros_like(n_samples)).to(torch.int32)
+            self._tail(dst, n_frames, T_out, seed, out)
         return out
 
 
@@ -114,14 +135,19 @@ class StoredFeaturePlan:
 
     def __init__(self, num_mel_bins, use_delta=True, spec_augment=None):
         sa = spec_augment or {}
-        if sa.get("W"):
-            raise NotImplementedError("SpecAugment time warping (W) is not supported (W is null in every shipped config)")
         enable = bool(spec_augment) and bool(sa.get("enable", True))
-        self.cfg = spec_augment_cfg(num_mel_bins, sa.get("F"), sa.get("m_F"), sa.get("T"), sa.get("p"), sa.get("m_T")) if enable \
-            else spec_augment_cfg(num_mel_bins)
-        self.num_mel_bins, self.use_delta = num_mel_bins, use_delta
+        self._sa = sa if enable else {}
+        self.W = int(sa.get("W") or 0) if enable else 0          # data.py:269: use_time_warping = bool(W)
+        self.use_delta = use_delta
         self.channels = 3 if use_delta else 1
         self._scratch = {}
+        self.set_num_features(num_mel_bins)
+
+    def set_num_features(self, v):
+        sa = self._sa
+        self.cfg = spec_augment_cfg(v, sa.get("F"), sa.get("m_F"), sa.get("T"), sa.get("p"), sa.get("m_T")) if (sa and v) \
+            else spec_augment_cfg(max(int(v), 1))
+        self.num_mel_bins = v
 
     def num_frames(self, n_frames: int) -> int:
         return n_frames
@@ -133,7 +159,7 @@ class StoredFeaturePlan:
         if out is None:
             out = torch.empty(B, T, self.num_mel_bins, self.channels, device=feats.device, dtype=torch.float32)
         src = feats
-        if self.cfg.sa_enable:
+        if self.cfg.sa_enable or self.W:
             if seed is None:
                 raise ValueError("StoredFeaturePlan: SpecAugment needs a device seed")
             if self.use_delta:
@@ -143,8 +169,12 @@ class StoredFeaturePlan:
                 src = self._scratch[key]
             else:
                 src = out.view(feats.shape)
-            src.copy_(feats)
-            spec_augment_(self.cfg, src.view(B, T, self.num_mel_bins, 1), n_frames, seed)
+            if self.W:                                           # the warp gathers: feats -> src, then masks in place
+                time_warp(feats.view(B, T, self.num_mel_bins, 1), n_frames, self.W, seed, src.view(B, T, self.num_mel_bins, 1))
+            else:
+                src.copy_(feats)
+            if self.cfg.sa_enable:
+                spec_augment_(self.cfg, src.view(B, T, self.num_mel_bins, 1), n_frames, seed)
         if self.use_delta:
             delta_accelerate(src, n_frames, out)
         elif src is feats:
@@ -167,6 +197,27 @@ def spec_augment_(cfg, x, n_frames, seed):
     assert x.dim() == 4 and x.is_contiguous() and x.shape[2] == cfg.num_mel_bins
     check(lib().asr_spec_augment(C.byref(cfg), _p(x), _p(n_frames), x.shape[0], x.shape[1], x.shape[3], _p(seed), _stream()))
     return x
+
+
+_tw_coef = {}
+
+
+def time_warp(x, n_frames, W, seed, out=None):
+    """SpecAugment time warping (data.py:275-280) of x [B, T, v, C] into `out` (a new tensor by default);
+    n_frames i32 [B] or None; seed: device i32/u32 [>=1]."""
+    _dev(x, name="x")
+    _dev(n_frames, torch.int32, "n_frames")
+    _dev(seed, torch.int32, "seed")
+    assert x.dim() == 4 and x.is_contiguous()
+    B, T, v, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.is_contiguous() and out.data_ptr() != x.data_ptr()
+    key = (B, x.device)
+    if key not in _tw_coef:
+        _tw_coef[key] = torch.zeros(B, 32, device=x.device, dtype=torch.float32)
+    check(lib().asr_time_warp(_p(x), _p(n_frames), B, T, v, Cc, int(W), _p(seed), _p(_tw_coef[key]), _p(out), _stream()))
+    return out
 
 
 def delta_accelerate(x, n_frames=None, out=None):

@@ -107,11 +107,6 @@ def test_spec_augment_matches_oracle_and_reference_bounds(sa):
     assert (out2 != out).any()
 
 
-def test_time_warp_is_rejected():
-    with pytest.raises(NotImplementedError):
-        _plan(spec_augment=dict(enable=True, W=80, F=27, m_F=1, T=100, p=1.0, m_T=1))
-
-
 # ---------------------------------------------------------------------------------------------- other feature types
 # parameter sets of the reference's tests/test_data.py:60-145 (shape checks there; values against the oracle here)
 @pytest.mark.parametrize("frame_length,frame_step,fft_length", [(1024, 1024, 1024), (128, 64, 256), (128, 80, None), (512, 512, 256)])
@@ -183,3 +178,60 @@ def test_data_config_feature_types():
         single = dc.audio_feature_fn(audio[0])
         assert tuple(single.shape) == (24, v, 1)
         assert torch.equal(single[:, :, 0], out[0, :, :, 0])
+
+
+# ---------------------------------------------------------------------------------------------- SpecAugment time warp
+def test_time_warp_kernel_vs_oracle():
+    from speech_recognition_amd import ops
+    B, T, v, W = 4, 234, 80, 40
+    g = np.random.default_rng(11)
+    x = g.uniform(0.1, 1.0, size=(B, T, v, 1)).astype(np.float32)
+    nf = np.array([T, 150, 81, 60], np.int32)                    # 60 <= 2W: copied unchanged
+    seed = 77
+    out = ops.time_warp(gpu(x), torch.from_numpy(nf).cuda(), W, torch.tensor([seed], dtype=torch.int32, device="cuda")).cpu().numpy()
+    for b in range(B):
+        tw = F.time_warp_params(seed, b, int(nf[b]), W)
+        ref = x[b].astype(np.float64).copy()
+        if tw is not None:
+            src, dst = tw
+            assert W <= src < nf[b] - W and -W <= dst - src < W      # the reference's draw ranges (data.py:276-277)
+            ref[:nf[b]] = F.time_warp(x[b, :nf[b]].astype(np.float64), src, dst)
+        else:
+            assert b == 3
+        assert np.abs(out[b] - ref).max() < 2e-3, (b, np.abs(out[b] - ref).max())
+        assert (out[b, nf[b]:] == x[b, nf[b]:]).all()            # padding frames untouched
+    assert np.abs(out[0] - x[0]).max() > 0.1                     # the warp did move something
+
+
+@pytest.mark.parametrize("W,Fm,m_F,Tm,p,m_T", [(80, 27, 1, 100, 1.0, 1), (40, 15, 2, 70, 0.2, 2)])
+def test_spec_augment_with_time_warp_reference_properties(W, Fm, m_F, Tm, p, m_T):
+    """tests/test_data.py:146-163 with the reference's own parameters (both use time warping)."""
+    from speech_recognition_amd.data import spec_augment
+    num_time, num_frequency = 234, 80
+    fn = spec_augment(num_frequency, W, Fm, m_F, Tm, p, m_T)
+    data = torch.rand(num_time, num_frequency, 1) * 0.9 + 0.1
+    augmented = fn(data, seed=5).cpu()
+    is_zero = (augmented == 0.0).all(dim=2)
+    assert int(is_zero.all(dim=0).sum()) <= Fm * m_F
+    assert int(is_zero.all(dim=1).sum()) <= Tm * m_T
+    assert augmented.shape == data.shape
+    assert bool((data != augmented).any())
+    assert float(augmented.max()) <= 1.0 + 1e-5 and float(augmented.min()) >= 0.0      # bilinear weights in [0, 1]
+
+
+def test_fused_plan_with_time_warp_vs_oracle():
+    B, n = 3, 16000 * 2
+    audio = _audio(B, n, 9)
+    ns = np.array([n, 24000, 320 + 160 * 99], np.int32)
+    sa = dict(W=20, F=9, m_F=2, T=12, p=0.5, m_T=2)
+    plan = _plan(spec_augment=dict(enable=True, **sa))
+    seed = torch.tensor([4321], dtype=torch.int32, device="cuda")
+    T_out = plan.num_frames(n) + 2
+    out = plan(gpu(audio), torch.from_numpy(ns).cuda(), T_out, seed)
+    ref = F.batch_features(audio.astype(np.float64), ns, LIBRI, seed=4321, spec_aug=sa, use_delta=True, T_out=T_out)
+    assert tuple(out.shape) == ref.shape
+    err = np.abs(out.cpu().numpy() - ref)
+    # the warp resamples log-mel frames whose neighbours differ by O(1): flow errors of 1e-4 frames become 1e-3 here
+    assert err.max() < 2e-2 and np.median(err) < 1e-4, (err.max(), np.median(err))
+    zero_ref = ref[..., 0] == 0.0
+    assert (out[..., 0].cpu().numpy()[zero_ref] == 0.0).all()
