@@ -26,6 +26,7 @@ import torch
 
 SAMPLE_RATE = 16000
 PEAK_F32_MFMA = 157.3e12   # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA = 2.5e15    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
@@ -43,8 +44,11 @@ WORKLOADS = {
     "las_large": dict(model="las_large.yml", clip_seconds=20.0, batch=64, tokens=128, flops=22.85e12,
                       metric="audio-seconds/sec training (las_large, 20s clips, bs64)",
                       text="las_large.yml + libri_config.yml, synthetic 20 s 16 kHz clips, batch 64 per GPU, 127 decoder steps, "
-                           "SpecAugment+delta on GPU, teacher forcing on, fwd+bwd+Adam(lr 2e-4); fp32 (north_star names bf16: not built)"),
+                           "SpecAugment+delta on GPU, teacher forcing on, fwd+bwd+Adam(lr 2e-4)", precision="bf16"),
 }
+PRECISION_TEXT = {"f32": "f32 throughout",
+                  "bf16": "mixed precision: dense contractions (gemm) with bf16 operands on the bf16 MFMA, f32 accumulation; "
+                          "recurrent cells, convolutions, softmax/CTC, BN, Adam and all storage f32"}
 
 
 def load_yaml(name):
@@ -213,8 +217,11 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="las_small")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default=None,
+                    help="default: f32 for las_small / deepspeech (the headline dtype), bf16 mixed precision for las_large (BASELINE configs[4])")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    precision = args.precision or wl.get("precision", "f32")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -283,6 +290,8 @@ def main():
         return trainer, model, dt, ev0.elapsed_time(ev1) / args.steps, stats, failed > 0
 
     from speech_recognition_amd import layers as _layers
+    from speech_recognition_amd import ops as _ops
+    _ops.set_mixed_precision(precision == "bf16")
     trainer, model, dt, dev_ms, (loss, correct, kept), failed = measure()
     if failed and _layers.PERSISTENT_RNN:
         # never report a step whose results are invalid: redo the whole measurement on the per-step recurrent
@@ -298,15 +307,16 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * wl["batch"] * wl["clip_seconds"] * args.steps / dt
     achieved = wl["flops"] / (dev_ms * 1e-3)
+    peak = PEAK_BF16_MFMA if precision == "bf16" else PEAK_F32_MFMA
     out = {
         "metric": wl["metric"], "value": round(value, 1), "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["text"], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
+        "config": {"workload": wl["text"] + "; " + PRECISION_TEXT[precision], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
                    "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "persistent_rnn": bool(_layers.PERSISTENT_RNN),
                    "final_loss": round(loss, 4)},
-        "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": wl.get("traffic"),
+        "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": wl.get("traffic") if precision == "f32" else None,
                      "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"},
     }
     if args.workload == "las_small" and world == 1:

@@ -110,6 +110,9 @@ typedef struct asr_gemm_desc {
   int a_rpg;
   const float* c_scale;        /* optional multiplier on C: c_scale[(row / c_rpg) * N + col]        */
   int c_rpg;
+  int compute;                 /* 0: f32 operands on the f32 MFMA (exact products); 1: mixed precision (train.py:62-66
+                                  --mixed-precision): operands rounded to bf16 (RNE) into the bf16 MFMA, f32
+                                  accumulation, f32 storage and epilogue                                       */
 } asr_gemm_desc;
 int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
 

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("batch", C.c_int), ("split_k", C.c_int), ("lda", c_long), ("ldb", c_long), ("ldc", c_long), ("stride_a", c_long),
                 ("stride_b", c_long), ("stride_c", c_long), ("stride_a_scale", c_long), ("alpha", C.c_float),
                 ("accumulate", C.c_int), ("relu", C.c_int), ("bias", c_f32p), ("a_scale", c_f32p), ("a_rpg", C.c_int),
-                ("c_scale", c_f32p), ("c_rpg", C.c_int)]
+                ("c_scale", c_f32p), ("c_rpg", C.c_int), ("compute", C.c_int)]
 
 
 class RnnGeom(C.Structure):

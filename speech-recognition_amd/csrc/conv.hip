@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Im2colLoader<VEC> al, Pla
   __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
-  T::run(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
+  T::template run<0>(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader<VEC> 
   const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
   if (kbeg >= K) return;
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
-  T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  T::template run<0>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 // all stride classes of one data-gradient in ONE launch (class = blockIdx.z): their tiles fill the chip
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs
       bl.Cc = kend;
     }
   }
-  T::run(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  T::template run<0>(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 static int conv_geom(const asr_conv_desc* d, ConvGeom* g) {

@@ -1,4 +1,5 @@
-// asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h).
+// asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h); desc.compute = 1 rounds the operands to
+// bf16 on their way into the bf16 MFMA (f32 storage, accumulation and epilogue: the mixed-precision mode).
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -16,7 +17,7 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int walk
   else { *bn = p / tiles_m; *bm = p - *bn * tiles_m; }
 }
 
-template <class AL, class BL, int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N>
+template <class AL, class BL, int TA, int TB, int BM, int BN, int WAVES_M, int WAVES_N, int BF>
 __global__ __launch_bounds__(256) void gemm_kernel(AL al, BL bl, GemmEpilogue ep, int K, long sAz, long sBz, long sCz, long sAscale,
                                                    int tiles_m, int tiles_n, int walk_n, int split_k, int k_chunk) {
   using T = GemmTile<TA, TB, BM, BN, WAVES_M, WAVES_N>;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(AL al, BL bl, GemmEpilogue ep
   if (kbeg >= K && !(K == 0 && zs == 0)) return;
   int bm, bn;
   tile_of_block(tiles_m, tiles_n, walk_n, &bm, &bn);
-  T::run(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  T::template run<BF>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 struct GemmPlan {
@@ -52,8 +53,12 @@ static void launch_cfg(const GemmPlan& g, const AL& al, const BL& bl) {
   // the operand with fewer bytes stays L2 resident; walk its tiles fastest
   const int walk_n = ((long)d->K * d->N <= (long)d->M * d->K) ? 1 : 0;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * sk));
-  hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
-                     d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
+  if (d->compute == 1)
+    hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N, 1>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
+                       d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
+  else
+    hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N, 0>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
+                       d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
 }
 
 template <class AL, class BL, int TA, int TB>
@@ -110,6 +115,7 @@ extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float*
             "asr_gemm_f32: leading dimension smaller than row length (lda %ld ldb %ld ldc %ld)", d->lda, d->ldb, d->ldc);
   ASR_CHECK((long)d->batch * (d->split_k > 1 ? d->split_k : 1) <= 65535, ASR_ERR_SHAPE, "asr_gemm_f32: batch*split_k > 65535");
   ASR_CHECK(!(d->split_k > 1 && !d->accumulate), ASR_ERR_ARG, "asr_gemm_f32: split_k > 1 accumulates atomically: set accumulate and pre-zero C");
+  ASR_CHECK(d->compute == 0 || d->compute == 1, ASR_ERR_ARG, "asr_gemm_f32: compute must be 0 (f32) or 1 (bf16 operands), got %d", d->compute);
   ASR_CHECK(!(d->a_scale && d->a_rpg <= 0) && !(d->c_scale && d->c_rpg <= 0), ASR_ERR_ARG,
             "asr_gemm_f32: group scale needs rows-per-group > 0");
   int mode = d->accumulate ? 1 : 0;

@@ -175,7 +175,10 @@ struct GemmTile {
   static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
   static_assert(256 % (BM / 4) == 0 && 256 % (BN / 4) == 0 && 256 % (BK / 4) == 0, "per-thread fixed fetch column");
 
-  template <class AL, class BL>
+  // BF = 1: the operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as they leave LDS and the
+  // products run on v_mfma_f32_32x32x16_bf16 with the same f32 accumulators - "mixed precision" with f32 storage,
+  // f32 accumulation and f32 epilogue.  One bf16 MFMA takes k = 16s + 8*(lane>>5) + j (j = 0..7) of the K tile.
+  template <int BF, class AL, class BL>
   static __device__ __forceinline__ void run(const AL& al, const BL& bl, const GemmEpilogue& ep, int kbeg, int kend,
                                              int m0, int n0, float* As, float* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -250,6 +253,47 @@ struct GemmTile {
       lstore();
       __syncthreads();
       if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+      if (BF) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8 a8[MI], b8[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int m = wm * WM + i * 32 + l31;
+            float t[8];
+            if (A_KC) {
+              const int q = 4 * s + 2 * lh;
+              const float4 u = As4[q * BM + (m ^ q)], w = As4[(q + 1) * BM + (m ^ (q + 1))];
+              t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w; t[4] = w.x; t[5] = w.y; t[6] = w.z; t[7] = w.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = As[(16 * s + 8 * lh + e) * BM + m];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a8[i][e] = (__bf16)t[e];
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int n = wn * WN + j * 32 + l31;
+            float t[8];
+            if (B_KC) {
+              const int q = 4 * s + 2 * lh;
+              const float4 u = Bs4[q * BN + (n ^ q)], w = Bs4[(q + 1) * BN + (n ^ (q + 1))];
+              t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w; t[4] = w.x; t[5] = w.y; t[6] = w.z; t[7] = w.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t[e] = Bs[(16 * s + 8 * lh + e) * BN + n];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[j][e] = (__bf16)t[e];
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         float a[MI][4], b[NI][4];
@@ -284,6 +328,7 @@ struct GemmTile {
 #pragma unroll
             for (int j = 0; j < NI; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
       }
       __syncthreads();
     }

@@ -240,10 +240,26 @@ def _mat(t, name):
     return t
 
 
+_compute = {"gemm": 0}
+
+
+def set_mixed_precision(on: bool):
+    """train.py:62-66 --mixed-precision on MI355X: every dense contraction that goes through `gemm` (input and
+    output projections, attention keys, vocabulary layer, and their gradients) rounds its operands to bf16 on the
+    way into the bf16 MFMA; storage, accumulation, epilogues, recurrent cells, convolutions, softmax / CTC,
+    batch norm and Adam stay f32 (f32 master weights).  A process-wide switch, like the Keras global policy."""
+    _compute["gemm"] = 1 if on else 0
+
+
+def mixed_precision() -> bool:
+    return bool(_compute["gemm"])
+
+
 def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias=None, relu=False, a_scale=None,
-         a_rpg=0, c_scale=None, c_rpg=0, split_k=1):
+         a_rpg=0, c_scale=None, c_rpg=0, split_k=1, compute=None):
     """c (+)= alpha * op(a) @ op(b) (+ bias).  2-D operands, or 3-D with a leading batch axis; a 2-D `c`
-    with 3-D a/b means split-K over the batch axis (atomic accumulation, requires accumulate)."""
+    with 3-D a/b means split-K over the batch axis (atomic accumulation, requires accumulate).
+    compute: None = the process-wide mode (set_mixed_precision), 0 = f32 operands, 1 = bf16 operands."""
     _mat(a, "a"), _mat(b, "b"), _mat(c, "c")
     batch = a.shape[0] if a.dim() == 3 else 1
     if b.dim() == 3 and a.dim() == 3:
@@ -273,6 +289,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     d.a_rpg = int(a_rpg)
     d.c_scale = c_scale.data_ptr() if c_scale is not None else None
     d.c_rpg = int(c_rpg)
+    d.compute = _compute["gemm"] if compute is None else int(compute)
     check(lib().asr_gemm_f32(C.byref(d), _p(a), _p(b), _p(c), _stream()))
     return c
 

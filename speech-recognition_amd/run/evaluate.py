@@ -1,7 +1,7 @@
 """`python -m speech_recognition_amd.run.evaluate` - speech_recognition/run/evaluate.py on MI355X: decode a
 dataset (greedy search, or beam search with --beam-size) with a trained model, report WER / CER, optionally write
 a (Prediction, Target, WER, CER) TSV.  Same flags as the reference.  --device
-must be GPU; --mixed-precision is accepted and has no effect (fp32 kernels)."""
+must be GPU; --mixed-precision selects bf16 operands for the dense contractions."""
 import argparse
 import csv
 import sys
@@ -31,7 +31,9 @@ def main(args: argparse.Namespace):
     get_device_strategy(args.device)
     logger = get_logger("inference")
     if args.mixed_precision:
-        logger.info("[!] --mixed-precision: this build computes in fp32 on the MFMA; the flag has no effect")
+        from .. import ops
+        ops.set_mixed_precision(True)
+        logger.info("[+] --mixed-precision: dense contractions use bf16 operands with f32 accumulation")
 
     logger.info(f"[+] Load Tokenizer from {args.sp_model_path}")
     tokenizer = SentencePieceTokenizer(args.sp_model_path, add_bos=True, add_eos=True)

@@ -1,6 +1,6 @@
 """`python -m speech_recognition_amd.run.inference` - speech_recognition/run/inference.py on MI355X: decode
 audio files (greedy search, or beam search with --beam-size) and write an (AudioPath, DecodedSentence) TSV.  Same
-flags as the reference; --device must be GPU, --mixed-precision has no effect."""
+flags as the reference; --device must be GPU, --mixed-precision selects bf16 operands for the dense contractions."""
 import argparse
 import csv
 import glob
@@ -32,7 +32,9 @@ def main(args: argparse.Namespace):
     get_device_strategy(args.device)
     logger = get_logger("inference")
     if args.mixed_precision:
-        logger.info("[!] --mixed-precision: this build computes in fp32 on the MFMA; the flag has no effect")
+        from .. import ops
+        ops.set_mixed_precision(True)
+        logger.info("[+] --mixed-precision: dense contractions use bf16 operands with f32 accumulation")
 
     tokenizer = SentencePieceTokenizer(args.sp_model_path, add_bos=True, add_eos=True)
     bos_id, eos_id = tokenizer.tokenize("").tolist()

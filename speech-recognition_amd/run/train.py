@@ -108,9 +108,12 @@ def main(cfg: TrainConfig, **extra):
         shutil.copy(cfg.model_config_path, path_join(cfg.output_path, "model-config.yml"))
 
     if cfg.mixed_precision:
-        # train.py:63-67 selects Keras' mixed_float16 policy.  This build's kernels are fp32 (MFMA f32);
-        # the flag is accepted so that existing command lines keep working, and says so.
-        logger.info("[!] --mixed-precision: this build computes in fp32 on the MFMA; the flag has no effect")
+        # train.py:63-67 selects Keras' mixed_float16 policy (bf16 on TPU).  Here: bf16 operands on the bf16 MFMA for
+        # every dense contraction, f32 accumulation, f32 master weights and f32 everywhere else; no loss scaling is
+        # needed (bf16 keeps the f32 exponent range).
+        from .. import ops
+        ops.set_mixed_precision(True)
+        logger.info("[+] --mixed-precision: dense contractions use bf16 operands with f32 accumulation (f32 weights and storage)")
 
     dc = cfg.data_config
     # Construct Dataset (host side: decode + tokenise only; features are computed on the GPU in the step)

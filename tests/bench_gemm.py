@@ -14,10 +14,15 @@ SHAPES = [  # (name, M, N, K, ta, tb, split_k)
     ("enc dX        NT", 7968, 608, 1024, 0, 1, 1), ("vocab dY      NT", 2048, 256, 16000, 0, 1, 8),
     ("enc dW        TN", 608, 1024, 7968, 1, 0, 19), ("vocab dW      TN", 256, 16000, 2048, 1, 0, 3), ("proj dW       TN", 512, 512, 7968, 1, 0, 48),
     ("square 4096   NN", 4096, 4096, 4096, 0, 0, 1),
+    ("large L1 in   NN", 31936, 4096, 2048, 0, 0, 1), ("large proj    NN", 31936, 2048, 2048, 0, 0, 1), ("large dX      NT", 31936, 2048, 4096, 0, 1, 1),
+    ("large dW      TN", 2048, 4096, 31936, 1, 0, 4),
 ]
 
 
 def main():
+    compute = 1 if "--bf16" in sys.argv else 0
+    ops.set_mixed_precision(bool(compute))
+    print("compute:", "bf16 operands" if compute else "f32")
     for name, M, N, K, ta, tb, sk in SHAPES:
         a = torch.randn((K, M) if ta else (M, K), device="cuda")
         b = torch.randn((N, K) if tb else (K, N), device="cuda")

@@ -83,3 +83,48 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm(a, b, c)
     with pytest.raises(ValueError):
         ops.gemm(a.cpu(), b, c)
+
+
+# ---------------------------------------------------------------------------------------------- mixed precision
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (7968 // 8, 512, 608), (33, 77, 19), (300, 32, 27), (16, 1000, 256)])
+def test_gemm_bf16_operands_f32_accumulate(ta, tb, M, N, K):
+    """compute=1: operands rounded to bf16 (round to nearest even) inside the kernel, products and sums in f32 -
+    so the result equals the float64 product of the ROUNDED operands to f32 accumulation accuracy, and differs
+    from the unrounded product by the bf16 rounding (2^-9 relative per operand)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N * 3 + K * 5 + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()         # torch rounds to nearest even as v_cvt_pk_bf16_f32 does
+    ref_r = (Ar.T if ta else Ar) @ (Br.T if tb else Br) + bias.double()
+    ref_x = (A.double().T if ta else A.double()) @ (B.double().T if tb else B.double()) + bias.double()
+    c = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(A.cuda(), B.cuda(), c, trans_a=bool(ta), trans_b=bool(tb), bias=bias.cuda(), compute=1)
+    assert_close(c, ref_r, 3e-6, f"bf16 gemm vs rounded operands ta={ta} tb={tb} {M}x{N}x{K}")
+    scale = float(ref_x.abs().max())
+    assert float((c.cpu().double() - ref_x).abs().max()) < 2e-2 * scale
+    c32 = torch.empty(M, N, device="cuda")
+    ops.gemm(A.cuda(), B.cuda(), c32, trans_a=bool(ta), trans_b=bool(tb), bias=bias.cuda(), compute=0)
+    assert_close(c32, ref_x, 2e-6, "compute=0 stays exact f32")
+
+
+def test_gemm_bf16_scaled_operand_splitk_and_switch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    M, N, K, rpg = 96, 80, 1000, 12
+    A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    asc = torch.rand(K // 8, M, generator=g)                      # a_scale on the stored (K x M) operand, 8 rows per group
+    As = (A * asc.repeat_interleave(8, 0)).bfloat16().double()    # the scale is applied in f32 before the rounding
+    ref = As.T @ B.bfloat16().double()
+    c = torch.zeros(M, N, device="cuda")
+    try:
+        ops.set_mixed_precision(True)
+        assert ops.mixed_precision()
+        ops.gemm(A.cuda(), B.cuda(), c, trans_a=True, accumulate=1, split_k=5, a_scale=asc.cuda(), a_rpg=8)
+    finally:
+        ops.set_mixed_precision(False)
+    assert_close(c, ref, 5e-6, "bf16 split-K with a_scale")
+    with pytest.raises(ValueError):
+        ops.gemm(A.cuda(), B.cuda(), c, trans_a=True, compute=3)

@@ -30,3 +30,28 @@ def test_shape_cache_is_bounded_and_eviction_is_transparent():
     bounded, unbounded = run(2), run(16)
     assert all(np.isfinite(bounded))
     np.testing.assert_allclose(bounded, unbounded, rtol=1e-4)    # same training trajectory with and without eviction
+
+
+def test_mixed_precision_tracks_f32():
+    """--mixed-precision (bf16 operands in the dense contractions, f32 accumulation and weights): logits and loss
+    gradients of LAS-mini stay within bf16 rounding of the f32 run on the same batch - and are not identical
+    (the switch does reach the kernels)."""
+    import torch
+
+    from speech_recognition_amd import ops
+    from tests import test_las_gpu as TL
+    cfg = TL.mk_cfg("lstm")
+    audio, tokens, _ = TL.inputs(B=4, T=38)
+    outs = {}
+    for mode in (False, True):
+        ops.set_mixed_precision(mode)
+        try:
+            m, _ = TL.build(cfg)
+            outs[mode] = m.forward(audio.cuda(), tokens.cuda().to(torch.int32)[:, :-1].contiguous(), training=False,
+                                   use_teacher_forcing=True).clone()
+        finally:
+            ops.set_mixed_precision(False)
+    a, b = outs[False], outs[True]
+    scale = float(a.abs().max())
+    diff = float((a - b).abs().max())
+    assert 0.0 < diff < 3e-2 * scale, (diff, scale)
