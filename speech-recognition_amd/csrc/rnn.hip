@@ -11,11 +11,17 @@
 // K split across the 4 waves and reduced through LDS; wave 0 then does the gate math.  Weights are
 // re-packed once per optimizer step into MFMA fragment order (asr_rnn_pack) so every B-operand
 // load is one coalesced 256-byte wave access of an L2-resident 16 KB slice.
+// (Measured and dropped for H = 1024, B = 64, where this tiling moves 256 MB of L2 -> CU traffic per step: a
+// "wide" variant - one workgroup per 8 units x all 64 rows, each weight read once, 96 MB per step - ran 46 us
+// per step with 4 waves and 63 us with 16 waves + LDS atomics against 36.7 us here; with one workgroup per CU
+// nothing hides the load latency, the 2048 small workgroups of this kernel do.)
 //
 // "slot" = one of the 16 packed gate columns: slot = 4*s + u, u = unit within the group,
 //   LSTM s = gate i,f,c~,o        GRU s = z, r, x-part of h~, recurrent part of h~        RNN s = 0 only.
 //
 // The backward step kernels live in rnn_bwd.hip (and rnn_persist_bwd.hip for whole layers).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CELL_LSTM 0
@@ -94,7 +100,44 @@ struct FwdDir {
 };
 struct FwdArgs { FwdDir d[2]; int B, H; const uint32_t* seed; };
 
-#define RNN_CH 4  // 16-wide K blocks a wave keeps in flight (loads first, then the MFMAs)
+#ifndef RNN_CH
+#define RNN_CH 4
+#endif  // 16-wide K blocks a wave keeps in flight (loads first, then the MFMAs)
+
+// Gate math of one (batch row b, hidden unit j) pair from the pre-activations `pre` (+ biases), the recurrent
+// sums s[4] (slot order of the packed weights) and the previous state; writes h / c / y / saved.
+template <int CELL>
+__device__ __forceinline__ void cell_finish(const FwdDir& d, int H, int b, int j, bool m, float hp, float yp, float cp, const float* pre,
+                                            const float* br, const float* s) {
+  float hn, cn = 0.f;
+  if (CELL == CELL_LSTM) {
+    const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
+    const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
+    const float c2 = fg * cp + ig * gg;
+    hn = og * tanhf_(c2);
+    cn = m ? c2 : cp;
+    if (d.saved) {
+      float* sv = d.saved + (long)b * d.saved_ld + j;
+      sv[0] = ig; sv[H] = fg; sv[2L * H] = gg; sv[3L * H] = og;
+    }
+    if (d.c_out) d.c_out[(long)b * d.c_out_ld + j] = cn;
+  } else if (CELL == CELL_GRU) {
+    const float z = sigmoidf_(pre[0] + s[0] + br[0]);
+    const float r = sigmoidf_(pre[1] + s[1] + br[1]);
+    const float arh = s[3] + br[2];
+    const float hh = tanhf_(pre[2] + s[2] + r * arh);
+    hn = z * hp + (1.f - z) * hh;
+    if (d.saved) {
+      float* sv = d.saved + (long)b * d.saved_ld + j;
+      sv[0] = z; sv[H] = r; sv[2L * H] = hh; sv[3L * H] = arh;
+    }
+  } else {
+    hn = tanhf_(pre[0] + s[0]);
+    if (d.saved) d.saved[(long)b * d.saved_ld + j] = hn;
+  }
+  if (d.h_out) d.h_out[(long)b * d.h_out_ld + j] = m ? hn : hp;
+  if (d.y_out) d.y_out[(long)b * d.y_out_ld + j] = m ? hn : yp;
+}
 
 template <int CELL>
 __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
@@ -190,34 +233,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     s[g] = part[0][bi * 17 + g * 4 + u] + part[1][bi * 17 + g * 4 + u] + part[2][bi * 17 + g * 4 + u] + part[3][bi * 17 + g * 4 + u];
-  float hn, cn = 0.f;
-  if (CELL == CELL_LSTM) {
-    const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
-    const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
-    const float c2 = fg * cp + ig * gg;
-    hn = og * tanhf_(c2);
-    cn = m ? c2 : cp;
-    if (d.saved) {
-      float* sv = d.saved + (long)b * d.saved_ld + j;
-      sv[0] = ig; sv[H] = fg; sv[2L * H] = gg; sv[3L * H] = og;
-    }
-    if (d.c_out) d.c_out[(long)b * d.c_out_ld + j] = cn;
-  } else if (CELL == CELL_GRU) {
-    const float z = sigmoidf_(pre[0] + s[0] + br[0]);
-    const float r = sigmoidf_(pre[1] + s[1] + br[1]);
-    const float arh = s[3] + br[2];
-    const float hh = tanhf_(pre[2] + s[2] + r * arh);
-    hn = z * hp + (1.f - z) * hh;
-    if (d.saved) {
-      float* sv = d.saved + (long)b * d.saved_ld + j;
-      sv[0] = z; sv[H] = r; sv[2L * H] = hh; sv[3L * H] = arh;
-    }
-  } else {
-    hn = tanhf_(pre[0] + s[0]);
-    if (d.saved) d.saved[(long)b * d.saved_ld + j] = hn;
-  }
-  if (d.h_out) d.h_out[(long)b * d.h_out_ld + j] = m ? hn : hp;
-  if (d.y_out) d.y_out[(long)b * d.y_out_ld + j] = m ? hn : yp;
+  cell_finish<CELL>(d, H, b, j, m, hp, yp, cp, pre, br, s);
 }
 
 // ------------------------------------------------------------------------------------------ host side

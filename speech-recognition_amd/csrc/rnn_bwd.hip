@@ -18,7 +18,9 @@
 #define CELL_GRU 1
 #define CELL_RNN 2
 #define BW_NW 16      // waves per workgroup
-#define BW_CH 4       // 16-column blocks a wave keeps in flight
+#ifndef BW_CH
+#define BW_CH 4
+#endif       // 16-column blocks a wave keeps in flight
 
 struct BackSrc {
   const float* D; long ldd;

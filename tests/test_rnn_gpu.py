@@ -24,7 +24,9 @@ def make_params(rt, D, H, g, scale=0.3):
 
 
 CASES = [("lstm", 5, 7, 6, 8), ("lstm", 23, 11, 8, 13), ("gru", 18, 9, 5, 20), ("rnn", 3, 5, 4, 6),
-         ("gru", 34, 6, 3, 111), ("lstm", 32, 40, 16, 256)]
+         ("gru", 34, 6, 3, 111), ("lstm", 32, 40, 16, 256),
+         # wide cells with several batch tiles (the LAS-large regime of the step kernels)
+         ("lstm", 40, 5, 8, 512), ("gru", 64, 4, 6, 516)]
 
 
 @pytest.mark.parametrize("rt,B,T,D,H", CASES)
