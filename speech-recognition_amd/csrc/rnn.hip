@@ -11,10 +11,7 @@
 // K split across the 4 waves and reduced through LDS; wave 0 then does the gate math.  Weights are
 // re-packed once per optimizer step into MFMA fragment order (asr_rnn_pack) so every B-operand
 // load is one coalesced 256-byte wave access of an L2-resident 16 KB slice.
-// (Measured and dropped for H = 1024, B = 64, where this tiling moves 256 MB of L2 -> CU traffic per step: a
-// "wide" variant - one workgroup per 8 units x all 64 rows, each weight read once, 96 MB per step - ran 46 us
-// per step with 4 waves and 63 us with 16 waves + LDS atomics against 36.7 us here; with one workgroup per CU
-// nothing hides the load latency, the 2048 small workgroups of this kernel do.)
+// (Wide cells with several batch tiles take rnn_step_fwd_wide_kernel below instead.)
 //
 // "slot" = one of the 16 packed gate columns: slot = 4*s + u, u = unit within the group,
 //   LSTM s = gate i,f,c~,o        GRU s = z, r, x-part of h~, recurrent part of h~        RNN s = 0 only.
@@ -236,6 +233,148 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
   cell_finish<CELL>(d, H, b, j, m, hp, yp, cp, pre, br, s);
 }
 
+// ------------------------------------------------------------------------------------------ wide forward step
+// Wide cells (H >= 512) with more than one batch tile (LAS-large: H = 1024, B = 64).  The narrow kernel above re-reads
+// every packed weight slice once per batch tile and the whole state once per 4 units: 256 MB of L2 -> CU traffic per step at
+// H = 1024, B = 64, which is what bounds it (36.9 us per step = 6.9 TB/s).  Here a workgroup owns WD_NQ weight slices
+// (4 * WD_NQ units) x NT batch tiles, K split over NW waves and reduced through LDS: 96 MB per step at NT = 2, WD_NQ = 4.
+// Occupancy matters as much as traffic - measured on las_large (ms per training step, narrow 255.3):
+//   NT,NQ,NW = 4,2,4: 276   2,2,4: 245.6   2,2,8: 232.2   2,2,16: 232.2   1,2,8: 237.9   4,2,16: 238.3   1,4,16: 227.4
+//   2,4,16: 225.5 (chosen: forward step 36.9 -> 23.6 us).  Summing the waves' partials with LDS atomics instead of a
+//   slab per wave was far slower (319).
+#define WD_CH 2
+
+template <int CELL, int NT, int WD_NQ, int NW>
+__global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wd_smem[];
+  float(*part)[NT][WD_NQ][16 * 17] = reinterpret_cast<float(*)[NT][WD_NQ][16 * 17]>(wd_smem);
+  const FwdDir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int H = a.H, B = a.B;
+  const int Q = (H + 3) >> 2, q0 = blockIdx.x * WD_NQ;
+  const int row0 = blockIdx.y * NT * 16;
+  constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
+  constexpr int NTHR = 64 * NW;
+  constexpr int NP = (NT * 16 * 4 * WD_NQ + NTHR - 1) / NTHR;    // (row, unit) pairs per thread
+
+  bool live[NP], m[NP];
+  float hp[NP], yp[NP], cp[NP], pre[NP][NG], br[NP][3];
+#pragma unroll
+  for (int r = 0; r < NP; ++r) {
+    const int p = tid + NTHR * r;
+    const int bl = p / (4 * WD_NQ), b = row0 + bl, uu = p % (4 * WD_NQ), j = 4 * (q0 + (uu >> 2)) + (uu & 3);
+    live[r] = b < B && bl < NT * 16 && j < H;
+    m[r] = true; hp[r] = 0.f; yp[r] = 0.f; cp[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) pre[r][g] = 0.f;
+    br[r][0] = br[r][1] = br[r][2] = 0.f;
+    if (live[r]) {
+      m[r] = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+      hp[r] = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+      yp[r] = d.y_prev ? d.y_prev[(long)b * d.y_prev_ld + j] : 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        float v = d.pre ? d.pre[(long)b * d.pre_ld + (long)g * H + j] : 0.f;
+        if (d.bias) v += d.bias[(long)g * H + j];
+        pre[r][g] = v;
+      }
+      if (CELL == CELL_LSTM) cp[r] = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+      if (CELL == CELL_GRU && d.bias_rec) { br[r][0] = d.bias_rec[j]; br[r][1] = d.bias_rec[H + j]; br[r][2] = d.bias_rec[2L * H + j]; }
+    }
+  }
+
+  f32x4 acc[NT][WD_NQ];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int qi = 0; qi < WD_NQ; ++qi) acc[t][qi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4* wp[WD_NQ];
+#pragma unroll
+  for (int qi = 0; qi < WD_NQ; ++qi) wp[qi] = reinterpret_cast<const float4*>(d.Wp) + (long)min(q0 + qi, Q - 1) * d.KSt * 64 + lane;
+  const uint32_t seedv = a.seed ? a.seed[0] : 0u;
+  for (int s = 0; s < d.nseg; ++s) {
+    const FwdSeg& sg = d.seg[s];
+    const int nb = (sg.K + 15) >> 4;
+    for (int j0 = wave; j0 < nb; j0 += NW * WD_CH) {
+      float4 av[WD_CH][NT], bv[WD_CH][WD_NQ];
+#pragma unroll
+      for (int i = 0; i < WD_CH; ++i) {
+        const int jb = j0 + NW * i;
+        const int k = 16 * jb + 4 * lq;
+#pragma unroll
+        for (int qi = 0; qi < WD_NQ; ++qi)
+          bv[i][qi] = (jb < nb && q0 + qi < Q) ? wp[qi][(long)(sg.ks0 + jb) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int brow = row0 + 16 * t + li;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (jb < nb && sg.x != nullptr && brow < B) {
+            const float* xr = sg.x + (long)brow * sg.ld;
+            if (sg.vec && k + 3 < sg.K) v = *reinterpret_cast<const float4*>(xr + k);
+            else {
+              v.x = k < sg.K ? xr[k] : 0.f;
+              v.y = k + 1 < sg.K ? xr[k + 1] : 0.f;
+              v.z = k + 2 < sg.K ? xr[k + 2] : 0.f;
+              v.w = k + 3 < sg.K ? xr[k + 3] : 0.f;
+            }
+          }
+          av[i][t] = v;
+        }
+      }
+      if (sg.drop) {
+        const AsrRngKey key = asr_rng_key(seedv, sg.drop_stream);
+        const uint32_t thr = asr_drop_threshold(sg.drop_rate);
+        const float dscale = 1.f / (1.f - sg.drop_rate);
+#pragma unroll
+        for (int i = 0; i < WD_CH; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const uint32_t idx = (uint32_t)((long)(row0 + 16 * t + li) * sg.drop_ld + sg.drop_off + 16 * (j0 + NW * i) + 4 * lq);
+            av[i][t].x *= asr_drop_mult(key, idx, thr, dscale);
+            av[i][t].y *= asr_drop_mult(key, idx + 1, thr, dscale);
+            av[i][t].z *= asr_drop_mult(key, idx + 2, thr, dscale);
+            av[i][t].w *= asr_drop_mult(key, idx + 3, thr, dscale);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < WD_CH; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int qi = 0; qi < WD_NQ; ++qi) {
+            acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].x, bv[i][qi].x, acc[t][qi], 0, 0, 0);
+            acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].y, bv[i][qi].y, acc[t][qi], 0, 0, 0);
+            acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].z, bv[i][qi].z, acc[t][qi], 0, 0, 0);
+            acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].w, bv[i][qi].w, acc[t][qi], 0, 0, 0);
+          }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int qi = 0; qi < WD_NQ; ++qi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][t][qi][(lq * 4 + r) * 17 + li] = acc[t][qi][r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NP; ++r) {
+    if (!live[r]) continue;
+    const int p = tid + NTHR * r;
+    const int bl = p / (4 * WD_NQ), b = row0 + bl, uu = p % (4 * WD_NQ), qi = uu >> 2, u = uu & 3, j = 4 * (q0 + qi) + u;
+    const int t = bl >> 4, bi = bl & 15;
+    float s4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += part[w][t][qi][bi * 17 + g * 4 + u];
+      s4[g] = v;
+    }
+    cell_finish<CELL>(d, H, b, j, m[r], hp[r], yp[r], cp[r], pre[r], br[r], s4);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static int cell_from_name(int rnn_type) { return rnn_type; }
 
@@ -283,7 +422,28 @@ static void fill_fwd_dir(FwdDir* d, const asr_rnn_step_fwd* s) {
   d->y_out = s->y_out; d->y_out_ld = s->y_out_ld; d->saved = s->saved; d->saved_ld = s->saved_ld;
 }
 
+template <int NT, int NQ, int NW>
+static void launch_fwd_wide(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) {
+  dim3 grid((unsigned)asr_cdiv(asr_cdiv(a.H, 4), NQ), (unsigned)asr_cdiv(a.B, 16 * NT), (unsigned)ndir);
+  const size_t smem = sizeof(float) * NW * NT * NQ * 16 * 17;
+  auto go = [&](auto kern) {
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, a);
+  };
+  if (rnn_type == CELL_LSTM) go(rnn_step_fwd_wide_kernel<CELL_LSTM, NT, NQ, NW>);
+  else if (rnn_type == CELL_GRU) go(rnn_step_fwd_wide_kernel<CELL_GRU, NT, NQ, NW>);
+  else go(rnn_step_fwd_wide_kernel<CELL_RNN, NT, NQ, NW>);
+}
+
 static int launch_fwd(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) {
+  // wide cells with several batch tiles: 16 units x 32 rows per workgroup (see rnn_step_fwd_wide_kernel); ASR_RNN_WIDE=0 turns it off
+  static const int wide = getenv("ASR_RNN_WIDE") ? atoi(getenv("ASR_RNN_WIDE")) : 1;
+  static const int min_h = getenv("ASR_RNN_WIDE_MIN_H") ? atoi(getenv("ASR_RNN_WIDE_MIN_H")) : 512;   // tests lower it
+  if (wide && a.H >= min_h && a.B > 16) {
+    launch_fwd_wide<2, 4, 16>(rnn_type, a, ndir, st);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+  }
   dim3 grid((unsigned)asr_cdiv(a.H, 4), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
   if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_fwd_kernel<CELL_LSTM>, grid, dim3(256), 0, st, a);
   else if (rnn_type == CELL_GRU) hipLaunchKernelGGL(rnn_step_fwd_kernel<CELL_GRU>, grid, dim3(256), 0, st, a);

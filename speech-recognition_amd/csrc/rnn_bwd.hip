@@ -12,6 +12,8 @@
 // data per launch - and a dependent launch on MI355X is priced mostly by the dirty lines it leaves.
 // A second "linear" mode of the same kernel only forms the sums (gradients of cell inputs that are
 // not states: the attention context, the initial states).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CELL_LSTM 0
@@ -86,57 +88,44 @@ __device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit
   return acc;
 }
 
+// Element-wise part of one backward step for the (batch row b, unit j) pair, from the two matrix-product sums.
+struct BwdOperands {
+  bool m;
+  float carry, svv[4], cpv, cov, dcv, hpv, addAv, addBv, dirv;
+};
+
 template <int CELL>
-__global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_kernel(Bwd2Args a) {
-  __shared__ float part[2][BW_NW][256];
-  const Bwd2Dir& d = a.d[blockIdx.z];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lq = lane >> 4;
-  const int unit0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-  const int B = a.B, H = d.n_units;
-  // thread (row, un) of the first 256 threads owns one (batch row, unit) pair for the gate math
-  const int row = tid >> 4, un = tid & 15;
-  const int b = b0 + row, j = unit0 + un;
-  const bool owner = tid < 256 && b < B && j < H;
-  const bool linear = d.out != nullptr;
-
-  // operands of the element-wise part: loads issued before the matrix products
+__device__ __forceinline__ void load_bwd_operands(const Bwd2Dir& d, int b, int j, int H, bool linear, BwdOperands& o) {
   constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
-  bool m = true;
-  float carry = 0.f, svv[NSV], cpv = 0.f, cov = 0.f, dcv = 0.f, hpv = 0.f, addAv = 0.f, addBv = 0.f, dirv = 0.f;
+  o.m = true; o.carry = 0.f; o.cpv = 0.f; o.cov = 0.f; o.dcv = 0.f; o.hpv = 0.f; o.addAv = 0.f; o.addBv = 0.f; o.dirv = 0.f;
 #pragma unroll
-  for (int g = 0; g < NSV; ++g) svv[g] = 0.f;
-  if (owner) {
-    if (d.addA) addAv = d.addA[(long)b * d.addA_ld + j];
-    if (d.addB) addBv = d.addB[(long)b * d.addB_ld + j];
-    if (d.direct) dirv = d.direct[(long)b * d.direct_ld + j];
-    if (!linear) {
-      m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
-      carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
-      const float* sv = d.saved + (long)b * d.saved_ld + j;
+  for (int g = 0; g < 4; ++g) o.svv[g] = 0.f;
+  if (d.addA) o.addAv = d.addA[(long)b * d.addA_ld + j];
+  if (d.addB) o.addBv = d.addB[(long)b * d.addB_ld + j];
+  if (d.direct) o.dirv = d.direct[(long)b * d.direct_ld + j];
+  if (!linear) {
+    o.m = d.mask ? d.mask[(long)b * d.mask_ld] != 0 : true;
+    o.carry = d.dy_carry ? d.dy_carry[(long)b * d.dy_carry_ld + j] : 0.f;
+    const float* sv = d.saved + (long)b * d.saved_ld + j;
 #pragma unroll
-      for (int g = 0; g < NSV; ++g) svv[g] = sv[(long)g * H];
-      if (CELL == CELL_LSTM) {
-        cpv = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
-        cov = d.c_out[(long)b * d.c_out_ld + j];
-        dcv = d.dc[(long)b * d.dc_ld + j];
-      }
-      if (CELL == CELL_GRU) hpv = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
+    for (int g = 0; g < NSV; ++g) o.svv[g] = sv[(long)g * H];
+    if (CELL == CELL_LSTM) {
+      o.cpv = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
+      o.cov = d.c_out[(long)b * d.c_out_ld + j];
+      o.dcv = d.dc[(long)b * d.dc_ld + j];
     }
+    if (CELL == CELL_GRU) o.hpv = d.h_prev ? d.h_prev[(long)b * d.h_prev_ld + j] : 0.f;
   }
+}
 
-  const f32x4 pa = back_partial(d.src[0], b0, unit0, B, H, wave, li, lq);
-  const f32x4 pb = back_partial(d.src[1], b0, unit0, B, H, wave, li, lq);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {        // C/D map: col = lane&15 (unit), row = 4*(lane>>4) + r (batch row)
-    part[0][wave][(lq * 4 + r) * 16 + li] = pa[r];
-    part[1][wave][(lq * 4 + r) * 16 + li] = pb[r];
-  }
-  __syncthreads();
-  if (!owner) return;
-  float sa = 0.f, sb = 0.f;
-#pragma unroll
-  for (int w = 0; w < BW_NW; ++w) { sa += part[0][w][tid]; sb += part[1][w][tid]; }
+template <int CELL>
+__device__ __forceinline__ void bwd_finish(const Bwd2Dir& d, const uint32_t* seed, int b, int j, int H, bool linear, const BwdOperands& op,
+                                           float sa, float sb) {
+  constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
+  const bool m = op.m;
+  const float carry = op.carry, cpv = op.cpv, cov = op.cov, dcv = op.dcv, hpv = op.hpv, addAv = op.addAv, addBv = op.addBv, dirv = op.dirv;
+  const float* svv = op.svv;
+  struct { const uint32_t* seed; } a{seed};
   if (d.src[1].D != nullptr && d.src[1].drop_rate > 0.f) {
     const BackSrc& s = d.src[1];
     const AsrRngKey key = asr_rng_key(a.seed[0], s.drop_stream);
@@ -184,6 +173,159 @@ __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_kernel(Bwd2Args a) {
   if (d.direct) d.direct[(long)b * d.direct_ld + j] = dir;
 }
 
+template <int CELL>
+__global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_kernel(Bwd2Args a) {
+  __shared__ float part[2][BW_NW][256];
+  const Bwd2Dir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int unit0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int B = a.B, H = d.n_units;
+  // thread (row, un) of the first 256 threads owns one (batch row, unit) pair for the gate math
+  const int row = tid >> 4, un = tid & 15;
+  const int b = b0 + row, j = unit0 + un;
+  const bool owner = tid < 256 && b < B && j < H;
+  const bool linear = d.out != nullptr;
+
+  // operands of the element-wise part: loads issued before the matrix products
+  BwdOperands op;
+  if (owner) load_bwd_operands<CELL>(d, b, j, H, linear, op);
+
+  const f32x4 pa = back_partial(d.src[0], b0, unit0, B, H, wave, li, lq);
+  const f32x4 pb = back_partial(d.src[1], b0, unit0, B, H, wave, li, lq);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {        // C/D map: col = lane&15 (unit), row = 4*(lane>>4) + r (batch row)
+    part[0][wave][(lq * 4 + r) * 16 + li] = pa[r];
+    part[1][wave][(lq * 4 + r) * 16 + li] = pb[r];
+  }
+  __syncthreads();
+  if (!owner) return;
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < BW_NW; ++w) { sa += part[0][w][tid]; sb += part[1][w][tid]; }
+  bwd_finish<CELL>(d, a.seed, b, j, H, linear, op, sa, sb);
+}
+
+// ------------------------------------------------------------------------------------------ wide backward step
+// Wide cells with several batch tiles (the mirror of rnn_step_fwd_wide_kernel, rnn.hip): a workgroup owns NU x 16 units
+// and NT x 16 batch rows, so a weight row is read once per NT tiles and a ds row once per NU tiles.  The column axis is
+// split over the 16 waves as above; every wave leaves one 16 x 16 slab per (source, row tile, unit tile) in LDS.
+// Measured on las_large (ms per training step, narrow kernel 225.9): NT,NU = 2,1: 219.6   1,2: 215.3 (chosen)
+// 2,2: 259.3   4,1: 276.1 - as in the forward kernel, tiles that leave fewer than one workgroup per CU lose more
+// to exposed latency than they save in L2 traffic.
+template <int NT, int NU>
+__device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int unit0, int B, int n_units, int wave, int li, int lq,
+                                                  f32x4 (&acc)[NT][NU]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s.D == nullptr) return;
+  for (int g = 0; g < s.nseg; ++g) {
+    const int len = s.len[g], nb = (len + 15) >> 4;
+    for (int j0 = wave; j0 < nb; j0 += BW_NW * 2) {
+      float4 av[2][NT], bv[2][NU];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int jb = j0 + BW_NW * i, k = 16 * jb + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int brow = b0 + 16 * t + li;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (jb < nb && brow < B) {
+            const float* dr = s.D + (long)brow * s.ldd + s.d_col0[g];
+            if (s.vec && k + 3 < len) v = *reinterpret_cast<const float4*>(dr + k);
+            else { v.x = k < len ? dr[k] : 0.f; v.y = k + 1 < len ? dr[k + 1] : 0.f; v.z = k + 2 < len ? dr[k + 2] : 0.f; v.w = k + 3 < len ? dr[k + 3] : 0.f; }
+          }
+          av[i][t] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int urow = unit0 + 16 * u + li;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (jb < nb && urow < n_units) {
+            const float* wr = s.W + (long)urow * s.ldw + s.w_col0[g];
+            if (s.vec && k + 3 < len) v = *reinterpret_cast<const float4*>(wr + k);
+            else { v.x = k < len ? wr[k] : 0.f; v.y = k + 1 < len ? wr[k + 1] : 0.f; v.z = k + 2 < len ? wr[k + 2] : 0.f; v.w = k + 3 < len ? wr[k + 3] : 0.f; }
+          }
+          bv[i][u] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].x, bv[i][u].x, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].y, bv[i][u].y, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].z, bv[i][u].z, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].w, bv[i][u].w, acc[t][u], 0, 0, 0);
+          }
+    }
+  }
+}
+
+template <int CELL, int NT, int NU>
+__global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_wide_kernel(Bwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float bw_smem[];   // [2 sources][BW_NW][NT * NU][256]
+  const Bwd2Dir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int unit0 = blockIdx.x * 16 * NU, b0 = blockIdx.y * 16 * NT;
+  const int B = a.B, H = d.n_units;
+  const bool linear = d.out != nullptr;
+  constexpr int NTHR = 64 * BW_NW, NPAIR = 256 * NT * NU, NP = (NPAIR + NTHR - 1) / NTHR;
+  constexpr int SLAB = NT * NU * 256;
+  const bool two = d.src[1].D != nullptr;
+
+  // pair p -> (row tile t, unit tile u, row, unit): p = ((t * NU + u) * 16 + row) * 16 + un  (= the slab layout)
+  BwdOperands op[NP];
+  bool owner[NP];
+#pragma unroll
+  for (int r = 0; r < NP; ++r) {
+    const int p = tid + NTHR * r;
+    const int tile = p >> 8, row = (p >> 4) & 15, un = p & 15;
+    const int b = b0 + 16 * (tile / NU) + row, j = unit0 + 16 * (tile % NU) + un;
+    owner[r] = p < NPAIR && b < B && j < H;
+    if (owner[r]) load_bwd_operands<CELL>(d, b, j, H, linear, op[r]);
+  }
+
+  f32x4 acc[NT][NU];
+  back_partial_wide<NT, NU>(d.src[0], b0, unit0, B, H, wave, li, lq, acc);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bw_smem[(long)wave * SLAB + (t * NU + u) * 256 + (lq * 4 + r) * 16 + li] = acc[t][u][r];
+  if (two) {
+    back_partial_wide<NT, NU>(d.src[1], b0, unit0, B, H, wave, li, lq, acc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bw_smem[(long)(BW_NW + wave) * SLAB + (t * NU + u) * 256 + (lq * 4 + r) * 16 + li] = acc[t][u][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NP; ++r) {
+    if (!owner[r]) continue;
+    const int p = tid + NTHR * r;
+    const int tile = p >> 8, row = (p >> 4) & 15, un = p & 15;
+    const int b = b0 + 16 * (tile / NU) + row, j = unit0 + 16 * (tile % NU) + un;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < BW_NW; ++w) sa += bw_smem[(long)w * SLAB + p];
+    if (two) {
+#pragma unroll
+      for (int w = 0; w < BW_NW; ++w) sb += bw_smem[(long)(BW_NW + w) * SLAB + p];
+    }
+    bwd_finish<CELL>(d, a.seed, b, j, H, linear, op[r], sa, sb);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static inline int cell_nsaved(int cell) { return cell == CELL_RNN ? 1 : 4; }
 
@@ -224,9 +366,41 @@ static int fill_dir(Bwd2Dir* d, const asr_rnn_step_bwd* s, int rnn_type, const u
   return ASR_OK;
 }
 
+template <int NT, int NU>
+static void launch_bwd_wide(int rnn_type, const Bwd2Args& a, int ndir, int nu, bool two, hipStream_t st) {
+  dim3 grid((unsigned)asr_cdiv(nu, 16 * NU), (unsigned)asr_cdiv(a.B, 16 * NT), (unsigned)ndir);
+  const size_t smem = sizeof(float) * (two ? 2 : 1) * BW_NW * NT * NU * 256;
+  auto go = [&](auto kern) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * BW_NW), smem, st, a);
+  };
+  if (rnn_type == CELL_LSTM) go(rnn_step_bwd_wide_kernel<CELL_LSTM, NT, NU>);
+  else if (rnn_type == CELL_GRU) go(rnn_step_bwd_wide_kernel<CELL_GRU, NT, NU>);
+  else go(rnn_step_bwd_wide_kernel<CELL_RNN, NT, NU>);
+}
+
 static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st) {
   int nu = a.d[0].n_units;
   for (int i = 1; i < ndir; ++i) nu = a.d[i].n_units > nu ? a.d[i].n_units : nu;
+  // wide cells with several batch tiles: 32 units x 16 rows per workgroup (rnn_step_bwd_wide_kernel); ASR_RNN_WIDE=0 turns it off
+  static const int wide = getenv("ASR_RNN_WIDE") ? atoi(getenv("ASR_RNN_WIDE")) : 1;
+  static const int min_h = getenv("ASR_RNN_WIDE_MIN_H") ? atoi(getenv("ASR_RNN_WIDE_MIN_H")) : 512;   // tests lower it
+  // ... and long rows to contract over (las_small's d context step has 512 units but only 1024 columns: narrow is faster there)
+  int cols = 0;
+  for (int i = 0; i < ndir; ++i)
+    for (int k = 0; k < 2; ++k) {
+      int c = 0;
+      for (int g = 0; g < a.d[i].src[k].nseg; ++g) c += a.d[i].src[k].D ? a.d[i].src[k].len[g] : 0;
+      cols = c > cols ? c : cols;
+    }
+  if (wide && nu >= min_h && a.B > 16 && (cols >= 2048 || min_h < 512)) {
+    bool two = false;
+    for (int i = 0; i < ndir; ++i) two = two || a.d[i].src[1].D != nullptr;
+    launch_bwd_wide<1, 2>(rnn_type, a, ndir, nu, two, st);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+  }
   dim3 grid((unsigned)asr_cdiv(nu, 16), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
   dim3 block(64 * BW_NW);
   if (rnn_type == CELL_LSTM) hipLaunchKernelGGL(rnn_step_bwd_kernel<CELL_LSTM>, grid, block, 0, st, a);
