@@ -1,8 +1,15 @@
 // asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h); desc.compute = 1 rounds the operands to
 // bf16 on their way into the bf16 MFMA (f32 storage, accumulation and epilogue: the mixed-precision mode).
+//
+// This file is compiled twice (the kernels dominate the library's build time): as gemm.hip with GEMM_BF = 0 (the f32
+// kernels and the C entry point) and through gemm_bf16.hip with GEMM_BF = 1 (the bf16-operand kernels).
 #include <stdlib.h>
 
 #include "gemm_core.h"
+
+#ifndef GEMM_BF
+#define GEMM_BF 0
+#endif
 
 // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share an
 // XCD's L2 - a speed assumption only), so the linear id is first remapped to p = (position of b inside
@@ -53,12 +60,8 @@ static void launch_cfg(const GemmPlan& g, const AL& al, const BL& bl) {
   // the operand with fewer bytes stays L2 resident; walk its tiles fastest
   const int walk_n = ((long)d->K * d->N <= (long)d->M * d->K) ? 1 : 0;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * sk));
-  if (d->compute == 1)
-    hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N, 1>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
-                       d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
-  else
-    hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N, 0>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
-                       d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
+  hipLaunchKernelGGL((gemm_kernel<AL, BL, TA, TB, BM, BN, WAVES_M, WAVES_N, GEMM_BF>), grid, dim3(256), 0, g.st, al, bl, g.ep, d->K, d->stride_a,
+                     d->stride_b, d->stride_c, d->stride_a_scale, tm, tn, walk_n, sk, k_chunk);
 }
 
 template <class AL, class BL, int TA, int TB>
@@ -103,6 +106,35 @@ static inline bool aligned16(const void* p, long ld, long stride) {
   return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (stride % 4 == 0);
 }
 
+#if GEMM_BF
+int asr_gemm_launch_bf16(const GemmPlan& g) {
+#else
+int asr_gemm_launch_bf16(const GemmPlan& g);
+static int asr_gemm_launch_f32(const GemmPlan& g) {
+#endif
+  const asr_gemm_desc* d = g.d;
+  const float* A = g.A;
+  const float* B = g.B;
+  const bool a_fast = d->K > 0 && aligned16(A, d->lda, d->stride_a) && g.a_cols % 4 == 0 && g.a_cols >= 4;
+  const bool b_fast = d->K > 0 && aligned16(B, d->ldb, d->stride_b) && g.b_cols % 4 == 0 && g.b_cols >= 4;
+  const bool s_fast = d->a_scale && (((uintptr_t)d->a_scale & 15) == 0) && d->stride_a_scale % 4 == 0 &&
+                      (long)g.a_rows * d->a_rpg < 4294967296L;
+  if (a_fast && b_fast && !d->a_scale) {
+    launch_l(g, FastLoader{A, d->lda, g.a_rows, g.a_cols}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
+  } else if (a_fast && b_fast && s_fast) {
+    const uint32_t magic = (uint32_t)((4294967296ULL + (uint64_t)d->a_rpg - 1) / (uint64_t)d->a_rpg);
+    launch_l(g, FastScaledLoader{A, d->lda, g.a_rows, g.a_cols, d->a_scale, magic}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
+  } else {
+    PlainLoader al{A, d->lda, g.a_rows, g.a_cols, aligned16(A, d->lda, d->stride_a), d->a_scale, d->a_rpg};
+    PlainLoader bl{B, d->ldb, g.b_rows, g.b_cols, aligned16(B, d->ldb, d->stride_b), nullptr, 1};
+    launch_l(g, al, bl);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+
+#if !GEMM_BF
 extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream) {
   ASR_CHECK(d && A && B && C, ASR_ERR_ARG, "asr_gemm_f32: null argument");
   ASR_CHECK(d->M > 0 && d->N > 0 && d->K >= 0 && d->batch >= 1, ASR_ERR_SHAPE, "asr_gemm_f32: bad M/N/K/batch %d %d %d %d",
@@ -126,20 +158,6 @@ extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float*
   if (d->accumulate == 2 || d->split_k > 1) mode = 2;
   g.ep = GemmEpilogue{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
 
-  const bool a_fast = d->K > 0 && aligned16(A, d->lda, d->stride_a) && g.a_cols % 4 == 0 && g.a_cols >= 4;
-  const bool b_fast = d->K > 0 && aligned16(B, d->ldb, d->stride_b) && g.b_cols % 4 == 0 && g.b_cols >= 4;
-  const bool s_fast = d->a_scale && (((uintptr_t)d->a_scale & 15) == 0) && d->stride_a_scale % 4 == 0 &&
-                      (long)g.a_rows * d->a_rpg < 4294967296L;
-  if (a_fast && b_fast && !d->a_scale) {
-    launch_l(g, FastLoader{A, d->lda, g.a_rows, g.a_cols}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
-  } else if (a_fast && b_fast && s_fast) {
-    const uint32_t magic = (uint32_t)((4294967296ULL + (uint64_t)d->a_rpg - 1) / (uint64_t)d->a_rpg);
-    launch_l(g, FastScaledLoader{A, d->lda, g.a_rows, g.a_cols, d->a_scale, magic}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});
-  } else {
-    PlainLoader al{A, d->lda, g.a_rows, g.a_cols, aligned16(A, d->lda, d->stride_a), d->a_scale, d->a_rpg};
-    PlainLoader bl{B, d->ldb, g.b_rows, g.b_cols, aligned16(B, d->ldb, d->stride_b), nullptr, 1};
-    launch_l(g, al, bl);
-  }
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
+  return d->compute == 1 ? asr_gemm_launch_bf16(g) : asr_gemm_launch_f32(g);
 }
+#endif
