@@ -12,6 +12,11 @@
 // The backward step mirrors them: dp = dctx . enc ; ds = p (dp - <p,dp>) ; dh = ds . Kq.
 // These kernels are latency-bound (a step moves ~25 MB): every wave issues the loads of several
 // independent rows before it reduces any of them.
+// Two one-launch variants were built, verified and dropped: splitting T over workgroups with an in-launch combine
+// (attention_fused.hip, opt-in: 17.5 us against 5 + 9 us) and, without any hand-off, one 16-wave workgroup per (row,
+// column chunk) that recomputes the row's scores itself (2, 4 or 8 chunks: las_small 16.99 -> 17.12-17.14 ms per step):
+// a single CU streaming its 320-510 KB through three dependent phases takes longer than the two wide launches plus
+// the 1.7 us boundary between them.
 #include "common.h"
 
 #define ATT_RPW 4   // rows per wave in the dot-product kernels
