@@ -174,8 +174,8 @@ def time_kernel(stream, fn, iters=20):
 
 
 def kernel_rooflines(trainer, model, audio_d, n_d):
-    """Per-kernel rooflines of the las_small step's three heaviest non-recurrent kernels, each timed alone on the
-    trainer's stream: the encoder input-projection GEMM (MFMA bound), the vocabulary GEMM (MFMA bound) and the
+    """Per-kernel rooflines of the las_small step: the three heaviest non-recurrent kernels and the persistent recurrent
+    sweep, each timed alone on the trainer's stream: the encoder input-projection GEMM (MFMA bound), the vocabulary GEMM (MFMA bound) and the
     fused front end (HBM bound, algorithmic bytes = SURVEY.md 8d: 160 KB per audio-second)."""
     from speech_recognition_amd import ops
     out = []
@@ -206,6 +206,21 @@ def kernel_rooflines(trainer, model, audio_d, n_d):
     byts = audio_d.numel() * 4 + feats.numel() * 4
     out.append({"kernel": "logmel_kernel (log-mel + SpecAugment + delta, fused)", "bound": "hbm", "achieved": round(byts / t / 1e9, 1),
                 "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(byts / t / PEAK_HBM, 4), "us": round(t * 1e6, 1)})
+    # the dominant kernel of the step: the persistent recurrent sweep (one launch per encoder layer).  It is bound by the
+    # latency of its T' dependent hand-offs, not by the matrix pipe: report both views
+    try:
+        from speech_recognition_amd import layers as _layers
+        buf = ws.layers[1]["rnn"]
+        if _layers.PERSISTENT_RNN and "persist_ws" in buf:
+            T2 = ws.T2
+            t = time_kernel(trainer.stream, lambda: ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"]), iters=5)
+            fl = 2.0 * B * T2 * He * 4 * He * 2
+            out.append({"kernel": f"rnn_seq_fwd_persist_kernel (BiLSTM layer, H={He}, B={B}, {T2} dependent steps in one launch)",
+                        "bound": "latency (reported against mfma)", "achieved": round(fl / t / 1e12, 2), "peak": PEAK_F32_MFMA / 1e12,
+                        "unit": "TFLOP/s", "frac": round(fl / t / PEAK_F32_MFMA, 4), "us": round(t * 1e6, 1),
+                        "us_per_dependent_step": round(t * 1e6 / T2, 2)})
+    except Exception as e:   # never take the measured line down
+        out.append({"kernel": "rnn_seq_fwd_persist_kernel", "error": str(e)})
     return out
 
 
