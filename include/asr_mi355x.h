@@ -253,6 +253,7 @@ int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const lon
 typedef struct asr_rnn_step_fwd {
   int nseg, KSt;
   const float* Wp;
+  const void* Wp16;                         /* optional bf16 image of Wp (asr_f32_to_bf16), same order: mixed precision  */
   const float* seg_x[ASR_RNN_MAXSEG];       /* inputs multiplying the packed weights              */
   long seg_ld[ASR_RNN_MAXSEG];
   int seg_K[ASR_RNN_MAXSEG], seg_ks0[ASR_RNN_MAXSEG];
@@ -274,6 +275,9 @@ typedef struct asr_rnn_step_fwd {
 } asr_rnn_step_fwd;
 int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fwd* steps, const uint32_t* seed,
                      void* stream);
+/* dst[i] = bf16(src[i]), round to nearest even: the bf16 weight images above (train.py:62-66 --mixed-precision:
+ * with them the wide step kernels multiply bf16 weights by bf16-rounded states on the bf16 MFMA, f32 accumulation) */
+int asr_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 
 /* Backward of one cell step.  The gradient handed from step to step is ds, the gradient wrt the gate
  * sums ([B, NS*H], written over the saved activations).  A source describes one consumer of this
@@ -284,6 +288,7 @@ int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fw
 typedef struct asr_rnn_back_src {
   const float* D; long ldd;                 /* consumer's ds rows (NULL: source unused)             */
   const float* W; long ldw;
+  const void* W16;                          /* optional bf16 image of W (same layout and ldw): mixed precision */
   int nseg; int d_col0[2], w_col0[2], len[2];
   float drop_rate; uint32_t drop_stream; long drop_ld; int drop_off; /* srcB only                  */
 } asr_rnn_back_src;
@@ -316,6 +321,7 @@ typedef struct asr_rnn_seq {
   const float* pre[2];
   const float* Wp[2];                       /* packed recurrent kernels (asr_rnn_pack)              */
   const float* U[2]; long ldu[2];           /* recurrent kernels [H, G*H] in the Keras layout (backward) */
+  const void* Wp16[2]; const void* U16[2];  /* optional bf16 images of Wp / U (mixed precision; used by the wide step kernels) */
   const float* bias_rec[2];                 /* GRU                                                   */
   const float* h0[2]; long h0_ld[2];        /* initial states (NULL = zeros)                         */
   const float* c0[2]; long c0_ld[2];

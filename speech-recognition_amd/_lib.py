@@ -37,7 +37,7 @@ class RnnGeom(C.Structure):
 
 
 class RnnStepFwd(C.Structure):
-    _fields_ = [("nseg", C.c_int), ("KSt", C.c_int), ("Wp", c_f32p),
+    _fields_ = [("nseg", C.c_int), ("KSt", C.c_int), ("Wp", c_f32p), ("Wp16", c_f32p),
                 ("seg_x", c_f32p * RNN_MAXSEG), ("seg_ld", c_long * RNN_MAXSEG),
                 ("seg_K", C.c_int * RNN_MAXSEG), ("seg_ks0", C.c_int * RNN_MAXSEG),
                 ("seg_drop_rate", C.c_float * RNN_MAXSEG), ("seg_drop_stream", C.c_uint32 * RNN_MAXSEG),
@@ -50,7 +50,7 @@ class RnnStepFwd(C.Structure):
 
 
 class RnnBackSrc(C.Structure):
-    _fields_ = [("D", c_f32p), ("ldd", c_long), ("W", c_f32p), ("ldw", c_long), ("nseg", C.c_int), ("d_col0", C.c_int * 2),
+    _fields_ = [("D", c_f32p), ("ldd", c_long), ("W", c_f32p), ("ldw", c_long), ("W16", c_f32p), ("nseg", C.c_int), ("d_col0", C.c_int * 2),
                 ("w_col0", C.c_int * 2), ("len", C.c_int * 2), ("drop_rate", C.c_float), ("drop_stream", C.c_uint32),
                 ("drop_ld", c_long), ("drop_off", C.c_int)]
 
@@ -68,6 +68,7 @@ class RnnStepBwd(C.Structure):
 class RnnSeq(C.Structure):
     _fields_ = [("rnn_type", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("ndir", C.c_int),
                 ("reverse", C.c_int * 2), ("pre", c_f32p * 2), ("Wp", c_f32p * 2), ("U", c_f32p * 2), ("ldu", c_long * 2),
+                ("Wp16", c_f32p * 2), ("U16", c_f32p * 2),
                 ("bias_rec", c_f32p * 2), ("h0", c_f32p * 2), ("h0_ld", c_long * 2), ("c0", c_f32p * 2),
                 ("c0_ld", c_long * 2), ("rec_mult", c_f32p * 2), ("mask", c_f32p),
                 ("hseq", c_f32p * 2), ("cseq", c_f32p * 2), ("y", c_f32p), ("y_ld", c_long), ("y_col", C.c_int * 2),
@@ -124,6 +125,7 @@ SIGNATURES = {
                                C.POINTER(C.c_int), _P, _P]),
     "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
     "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
+    "asr_f32_to_bf16": (C.c_int, [_P, _P, c_long, _P]),
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),

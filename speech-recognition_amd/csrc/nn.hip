@@ -360,3 +360,32 @@ extern "C" int asr_token_mask(const int32_t* tok, long n, int pad, uint8_t* out,
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------ bf16 weight images
+// dst[i] = bf16(src[i]) (round to nearest even): the images the wide recurrent step kernels read under mixed precision.
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 o;
+      o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(dst + i) = o;
+    } else {
+      for (long k = i; k < n; ++k) dst[k] = (__bf16)src[k];
+    }
+  }
+}
+
+extern "C" int asr_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+  ASR_CHECK(src && dst, ASR_ERR_ARG, "asr_f32_to_bf16: null argument");
+  ASR_CHECK(n > 0, ASR_ERR_SHAPE, "asr_f32_to_bf16: n must be > 0");
+  ASR_CHECK((((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 7) == 0), ASR_ERR_ARG, "asr_f32_to_bf16: src must be 16-byte and dst 8-byte aligned");
+  const long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(256), 0, (hipStream_t)stream, src,
+                     static_cast<__bf16*>(dst), n);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

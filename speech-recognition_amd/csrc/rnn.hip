@@ -84,6 +84,7 @@ struct FwdDir {
   FwdSeg seg[ASR_RNN_MAXSEG];
   int nseg, KSt;
   const float* Wp;
+  const unsigned short* Wp16;   // bf16 image of Wp or NULL
   const float* pre; long pre_ld;
   const float* bias; const float* bias_rec;
   const float* h_prev; long h_prev_ld;
@@ -244,7 +245,11 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
 //   slab per wave was far slower (319).
 #define WD_CH 2
 
-template <int CELL, int NT, int WD_NQ, int NW>
+// WBF = 1 (mixed precision): the weights come from their bf16 image and the inputs are rounded to bf16 in registers; one
+// v_mfma_f32_16x16x32_bf16 then covers the two 16-wide K blocks a wave has in flight (the k labelling inside an MFMA
+// is free as long as both operands agree: elements 0-3 of a lane's fragment are its float4 of the first block,
+// elements 4-7 that of the second) - an eighth of the matrix-pipe time and half the weight bytes.
+template <int CELL, int NT, int WD_NQ, int NW, int WBF>
 __global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wd_smem[];
   float(*part)[NT][WD_NQ][16 * 17] = reinterpret_cast<float(*)[NT][WD_NQ][16 * 17]>(wd_smem);
@@ -290,21 +295,28 @@ __global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
 #pragma unroll
     for (int qi = 0; qi < WD_NQ; ++qi) acc[t][qi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float4* wp[WD_NQ];
+  const uint2* wp16[WD_NQ];
 #pragma unroll
-  for (int qi = 0; qi < WD_NQ; ++qi) wp[qi] = reinterpret_cast<const float4*>(d.Wp) + (long)min(q0 + qi, Q - 1) * d.KSt * 64 + lane;
+  for (int qi = 0; qi < WD_NQ; ++qi) {
+    wp[qi] = reinterpret_cast<const float4*>(d.Wp) + (long)min(q0 + qi, Q - 1) * d.KSt * 64 + lane;
+    wp16[qi] = reinterpret_cast<const uint2*>(d.Wp16) + (long)min(q0 + qi, Q - 1) * d.KSt * 64 + lane;
+  }
   const uint32_t seedv = a.seed ? a.seed[0] : 0u;
   for (int s = 0; s < d.nseg; ++s) {
     const FwdSeg& sg = d.seg[s];
     const int nb = (sg.K + 15) >> 4;
     for (int j0 = wave; j0 < nb; j0 += NW * WD_CH) {
-      float4 av[WD_CH][NT], bv[WD_CH][WD_NQ];
+      float4 av[WD_CH][NT], bv[WBF ? 1 : WD_CH][WD_NQ];
+      uint2 bh[WD_CH][WD_NQ];
 #pragma unroll
       for (int i = 0; i < WD_CH; ++i) {
         const int jb = j0 + NW * i;
         const int k = 16 * jb + 4 * lq;
 #pragma unroll
-        for (int qi = 0; qi < WD_NQ; ++qi)
-          bv[i][qi] = (jb < nb && q0 + qi < Q) ? wp[qi][(long)(sg.ks0 + jb) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int qi = 0; qi < WD_NQ; ++qi) {
+          if (WBF) bh[i][qi] = (jb < nb && q0 + qi < Q) ? wp16[qi][(long)(sg.ks0 + jb) * 64] : make_uint2(0u, 0u);
+          else bv[i][qi] = (jb < nb && q0 + qi < Q) ? wp[qi][(long)(sg.ks0 + jb) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int brow = row0 + 16 * t + li;
@@ -337,6 +349,24 @@ __global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
             av[i][t].w *= asr_drop_mult(key, idx + 3, thr, dscale);
           }
       }
+      if (WBF) {
+        static_assert(WD_CH == 2, "one bf16 MFMA per pair of blocks");
+        bf16x8 a8[NT], b8[WD_NQ];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          a8[t][0] = (__bf16)av[0][t].x; a8[t][1] = (__bf16)av[0][t].y; a8[t][2] = (__bf16)av[0][t].z; a8[t][3] = (__bf16)av[0][t].w;
+          a8[t][4] = (__bf16)av[1][t].x; a8[t][5] = (__bf16)av[1][t].y; a8[t][6] = (__bf16)av[1][t].z; a8[t][7] = (__bf16)av[1][t].w;
+        }
+#pragma unroll
+        for (int qi = 0; qi < WD_NQ; ++qi) {
+          const uint4 raw = make_uint4(bh[0][qi].x, bh[0][qi].y, bh[1][qi].x, bh[1][qi].y);
+          b8[qi] = __builtin_bit_cast(bf16x8, raw);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int qi = 0; qi < WD_NQ; ++qi) acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[t], b8[qi], acc[t][qi], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int i = 0; i < WD_CH; ++i)
 #pragma unroll
@@ -348,6 +378,7 @@ __global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
             acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].z, bv[i][qi].z, acc[t][qi], 0, 0, 0);
             acc[t][qi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t].w, bv[i][qi].w, acc[t][qi], 0, 0, 0);
           }
+      }
     }
   }
 #pragma unroll
@@ -408,7 +439,7 @@ extern "C" int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W
 
 static void fill_fwd_dir(FwdDir* d, const asr_rnn_step_fwd* s) {
   *d = FwdDir{};
-  d->nseg = s->nseg; d->KSt = s->KSt; d->Wp = s->Wp;
+  d->nseg = s->nseg; d->KSt = s->KSt; d->Wp = s->Wp; d->Wp16 = static_cast<const unsigned short*>(s->Wp16);
   for (int i = 0; i < s->nseg; ++i) {
     d->seg[i].x = s->seg_x[i]; d->seg[i].ld = s->seg_ld[i]; d->seg[i].K = s->seg_K[i]; d->seg[i].ks0 = s->seg_ks0[i];
     d->seg[i].vec = (((uintptr_t)s->seg_x[i] & 15) == 0) && (s->seg_ld[i] % 4 == 0);
@@ -431,9 +462,17 @@ static void launch_fwd_wide(int rnn_type, const FwdArgs& a, int ndir, hipStream_
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, a);
   };
-  if (rnn_type == CELL_LSTM) go(rnn_step_fwd_wide_kernel<CELL_LSTM, NT, NQ, NW>);
-  else if (rnn_type == CELL_GRU) go(rnn_step_fwd_wide_kernel<CELL_GRU, NT, NQ, NW>);
-  else go(rnn_step_fwd_wide_kernel<CELL_RNN, NT, NQ, NW>);
+  bool bf = true;
+  for (int i = 0; i < ndir; ++i) bf = bf && a.d[i].Wp16 != nullptr;
+  if (bf) {
+    if (rnn_type == CELL_LSTM) go(rnn_step_fwd_wide_kernel<CELL_LSTM, NT, NQ, NW, 1>);
+    else if (rnn_type == CELL_GRU) go(rnn_step_fwd_wide_kernel<CELL_GRU, NT, NQ, NW, 1>);
+    else go(rnn_step_fwd_wide_kernel<CELL_RNN, NT, NQ, NW, 1>);
+    return;
+  }
+  if (rnn_type == CELL_LSTM) go(rnn_step_fwd_wide_kernel<CELL_LSTM, NT, NQ, NW, 0>);
+  else if (rnn_type == CELL_GRU) go(rnn_step_fwd_wide_kernel<CELL_GRU, NT, NQ, NW, 0>);
+  else go(rnn_step_fwd_wide_kernel<CELL_RNN, NT, NQ, NW, 0>);
 }
 
 static int launch_fwd(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) {
@@ -493,7 +532,7 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
       const int tp = rev ? t + 1 : t - 1;  // time index of the previous processing step
       FwdDir& fd = a.d[d];
       fd = FwdDir{};
-      fd.nseg = 1; fd.KSt = g.KSt; fd.Wp = s->Wp[d];
+      fd.nseg = 1; fd.KSt = g.KSt; fd.Wp = s->Wp[d]; fd.Wp16 = static_cast<const unsigned short*>(s->Wp16[d]);
       fd.pre = s->pre[d] + (long)t * NG * H; fd.pre_ld = (long)T * NG * H;
       fd.bias = nullptr; fd.bias_rec = s->bias_rec[d];
       float* hseq = s->hseq[d];

@@ -27,6 +27,7 @@
 struct BackSrc {
   const float* D; long ldd;
   const float* W; long ldw;
+  const unsigned short* W16;     // bf16 image of W (same layout) or NULL
   int nseg; int d_col0[2], w_col0[2], len[2];
   int vec;
   float drop_rate; uint32_t drop_stream; long drop_ld; int drop_off;
@@ -213,7 +214,9 @@ __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_kernel(Bwd2Args a) {
 // Measured on las_large (ms per training step, narrow kernel 225.9): NT,NU = 2,1: 219.6   1,2: 215.3 (chosen)
 // 2,2: 259.3   4,1: 276.1 - as in the forward kernel, tiles that leave fewer than one workgroup per CU lose more
 // to exposed latency than they save in L2 traffic.
-template <int NT, int NU>
+// WBF = 1 (mixed precision): weights from the bf16 image, ds rounded to bf16 in registers, one v_mfma_f32_16x16x32_bf16 per
+// pair of column blocks (see rnn_step_fwd_wide_kernel).
+template <int NT, int NU, int WBF>
 __device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int unit0, int B, int n_units, int wave, int li, int lq,
                                                   f32x4 (&acc)[NT][NU]) {
 #pragma unroll
@@ -224,7 +227,8 @@ __device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int 
   for (int g = 0; g < s.nseg; ++g) {
     const int len = s.len[g], nb = (len + 15) >> 4;
     for (int j0 = wave; j0 < nb; j0 += BW_NW * 2) {
-      float4 av[2][NT], bv[2][NU];
+      float4 av[2][NT], bv[WBF ? 1 : 2][NU];
+      uint2 bh[2][NU];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int jb = j0 + BW_NW * i, k = 16 * jb + 4 * lq;
@@ -242,15 +246,45 @@ __device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
           const int urow = unit0 + 16 * u + li;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (jb < nb && urow < n_units) {
-            const float* wr = s.W + (long)urow * s.ldw + s.w_col0[g];
-            if (s.vec && k + 3 < len) v = *reinterpret_cast<const float4*>(wr + k);
-            else { v.x = k < len ? wr[k] : 0.f; v.y = k + 1 < len ? wr[k + 1] : 0.f; v.z = k + 2 < len ? wr[k + 2] : 0.f; v.w = k + 3 < len ? wr[k + 3] : 0.f; }
+          if (WBF) {
+            uint2 h = make_uint2(0u, 0u);
+            if (jb < nb && urow < n_units) {
+              const unsigned short* wr = s.W16 + (long)urow * s.ldw + s.w_col0[g];
+              if (s.vec && k + 3 < len) h = *reinterpret_cast<const uint2*>(wr + k);
+              else {
+                const unsigned w0 = k < len ? wr[k] : 0u, w1 = k + 1 < len ? wr[k + 1] : 0u, w2 = k + 2 < len ? wr[k + 2] : 0u, w3 = k + 3 < len ? wr[k + 3] : 0u;
+                h = make_uint2(w0 | (w1 << 16), w2 | (w3 << 16));
+              }
+            }
+            bh[i][u] = h;
+          } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jb < nb && urow < n_units) {
+              const float* wr = s.W + (long)urow * s.ldw + s.w_col0[g];
+              if (s.vec && k + 3 < len) v = *reinterpret_cast<const float4*>(wr + k);
+              else { v.x = k < len ? wr[k] : 0.f; v.y = k + 1 < len ? wr[k + 1] : 0.f; v.z = k + 2 < len ? wr[k + 2] : 0.f; v.w = k + 3 < len ? wr[k + 3] : 0.f; }
+            }
+            bv[i][u] = v;
           }
-          bv[i][u] = v;
         }
       }
+      if (WBF) {
+        bf16x8 a8[NT], b8[NU];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          a8[t][0] = (__bf16)av[0][t].x; a8[t][1] = (__bf16)av[0][t].y; a8[t][2] = (__bf16)av[0][t].z; a8[t][3] = (__bf16)av[0][t].w;
+          a8[t][4] = (__bf16)av[1][t].x; a8[t][5] = (__bf16)av[1][t].y; a8[t][6] = (__bf16)av[1][t].z; a8[t][7] = (__bf16)av[1][t].w;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const uint4 raw = make_uint4(bh[0][u].x, bh[0][u].y, bh[1][u].x, bh[1][u].y);
+          b8[u] = __builtin_bit_cast(bf16x8, raw);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int u = 0; u < NU; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[t], b8[u], acc[t][u], 0, 0, 0);
+      } else
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -266,7 +300,7 @@ __device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int 
   }
 }
 
-template <int CELL, int NT, int NU>
+template <int CELL, int NT, int NU, int WBF>
 __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_wide_kernel(Bwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) float bw_smem[];   // [2 sources][BW_NW][NT * NU][256]
   const Bwd2Dir& d = a.d[blockIdx.z];
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_wide_kernel(Bwd2Args 
   }
 
   f32x4 acc[NT][NU];
-  back_partial_wide<NT, NU>(d.src[0], b0, unit0, B, H, wave, li, lq, acc);
+  back_partial_wide<NT, NU, WBF>(d.src[0], b0, unit0, B, H, wave, li, lq, acc);
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -300,7 +334,7 @@ __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_wide_kernel(Bwd2Args 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bw_smem[(long)wave * SLAB + (t * NU + u) * 256 + (lq * 4 + r) * 16 + li] = acc[t][u][r];
   if (two) {
-    back_partial_wide<NT, NU>(d.src[1], b0, unit0, B, H, wave, li, lq, acc);
+    back_partial_wide<NT, NU, WBF>(d.src[1], b0, unit0, B, H, wave, li, lq, acc);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -334,6 +368,7 @@ static int fill_src(BackSrc* o, const asr_rnn_back_src* s) {
   if (!s->D) return ASR_OK;
   ASR_CHECK(s->W && s->nseg >= 1 && s->nseg <= 2, ASR_ERR_ARG, "rnn backward source: weights / segments missing");
   o->D = s->D; o->ldd = s->ldd; o->W = s->W; o->ldw = s->ldw; o->nseg = s->nseg;
+  o->W16 = static_cast<const unsigned short*>(s->W16);
   bool vec = (((uintptr_t)s->D | (uintptr_t)s->W) & 15) == 0 && s->ldd % 4 == 0 && s->ldw % 4 == 0;
   for (int g = 0; g < s->nseg; ++g) {
     o->d_col0[g] = s->d_col0[g]; o->w_col0[g] = s->w_col0[g]; o->len[g] = s->len[g];
@@ -375,9 +410,18 @@ static void launch_bwd_wide(int rnn_type, const Bwd2Args& a, int ndir, int nu, b
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(kern, grid, dim3(64 * BW_NW), smem, st, a);
   };
-  if (rnn_type == CELL_LSTM) go(rnn_step_bwd_wide_kernel<CELL_LSTM, NT, NU>);
-  else if (rnn_type == CELL_GRU) go(rnn_step_bwd_wide_kernel<CELL_GRU, NT, NU>);
-  else go(rnn_step_bwd_wide_kernel<CELL_RNN, NT, NU>);
+  bool bf = true;                                                // every used source carries a bf16 image of its weights
+  for (int i = 0; i < ndir; ++i)
+    for (int k = 0; k < 2; ++k) bf = bf && (a.d[i].src[k].D == nullptr || a.d[i].src[k].W16 != nullptr);
+  if (bf) {
+    if (rnn_type == CELL_LSTM) go(rnn_step_bwd_wide_kernel<CELL_LSTM, NT, NU, 1>);
+    else if (rnn_type == CELL_GRU) go(rnn_step_bwd_wide_kernel<CELL_GRU, NT, NU, 1>);
+    else go(rnn_step_bwd_wide_kernel<CELL_RNN, NT, NU, 1>);
+    return;
+  }
+  if (rnn_type == CELL_LSTM) go(rnn_step_bwd_wide_kernel<CELL_LSTM, NT, NU, 0>);
+  else if (rnn_type == CELL_GRU) go(rnn_step_bwd_wide_kernel<CELL_GRU, NT, NU, 0>);
+  else go(rnn_step_bwd_wide_kernel<CELL_RNN, NT, NU, 0>);
 }
 
 static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st) {
@@ -464,7 +508,7 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
       if (tn_step <= T - 1) {
         const int tn = rev ? T - 1 - tn_step : tn_step;
         sb.srcA.D = s->saved[d] + (long)tn * NS * H; sb.srcA.ldd = ld_s;
-        sb.srcA.W = s->U[d]; sb.srcA.ldw = s->ldu[d] ? s->ldu[d] : (long)NG * H;
+        sb.srcA.W = s->U[d]; sb.srcA.ldw = s->ldu[d] ? s->ldu[d] : (long)NG * H; sb.srcA.W16 = s->U16[d];
         rec_segments(s->rnn_type, H, &sb.srcA);
       } else {
         sb.addA = gs->dh_last[d]; sb.addA_ld = gs->dh_last_ld[d];

@@ -122,6 +122,8 @@ class DeepSpeech2(ModelProto):
         self._version += 1
 
     def pack_weights(self):
+        if ops.mixed_precision():
+            self.store.refresh_bf16()
         for l in self.layers:
             l.pack()
         self._packed_version = self._version

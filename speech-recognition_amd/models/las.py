@@ -200,6 +200,8 @@ class LAS(ModelProto):
     def pack_weights(self):
         """Refresh the MFMA-fragment images of every recurrent weight (cheap; once per optimizer step)."""
         p = self.store.p
+        if ops.mixed_precision():
+            self.store.refresh_bf16()
         for l in self.enc_layers:
             l.pack()
         for j, cell in enumerate(self.dec_cells):
@@ -375,7 +377,7 @@ class LAS(ModelProto):
             b = p[pre + "bias"]
             st = _lib.RnnStepFwd()
             g = cell.geom
-            st.nseg, st.KSt, st.Wp = 2, g.KSt, cell.Wp.data_ptr()
+            st.nseg, st.KSt, st.Wp, st.Wp16 = 2, g.KSt, cell.Wp.data_ptr(), cell.wp16_ptr()
             x = ws.ctx[i] if j == 0 else ws.dec[j - 1]["y"][i]
             Kx = 2 * He if j == 0 else Hd
             st.seg_x[0], st.seg_ld[0], st.seg_K[0], st.seg_ks0[0] = x.data_ptr(), x.stride(0), Kx, g.ks0[0]

@@ -255,6 +255,36 @@ def mixed_precision() -> bool:
     return bool(_compute["gemm"])
 
 
+# bf16 images of f32 weight buffers (the flat parameter buffer of a model): the wide recurrent step kernels read their
+# weights from the image when the mixed-precision switch is on.  (flat f32 tensor, bf16 image of the same length)
+_mirrors = []
+
+
+def register_bf16_mirror(flat: torch.Tensor, image: torch.Tensor):
+    _mirrors[:] = [(f, m) for f, m in _mirrors if f.data_ptr() != flat.data_ptr()]
+    _mirrors.append((flat, image))
+
+
+def bf16_twin(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Address of the bf16 image of the f32 view `t` (same element offset inside a registered mirror), or None."""
+    if t is None or not _compute["gemm"]:
+        return None
+    ptr = t.data_ptr()
+    for flat, image in _mirrors:
+        base = flat.data_ptr()
+        if base <= ptr < base + flat.numel() * 4:
+            return image.data_ptr() + (ptr - base) // 2
+    return None
+
+
+def f32_to_bf16(src: torch.Tensor, dst: torch.Tensor):
+    """dst (bfloat16, same numel) = round-to-nearest-even of src (float32), on the current stream."""
+    _dev(src, name="src")
+    assert dst.dtype == torch.bfloat16 and dst.numel() == src.numel() and src.is_contiguous() and dst.is_contiguous()
+    check(lib().asr_f32_to_bf16(_p(src), C.c_void_p(dst.data_ptr()), src.numel(), _stream()))
+    return dst
+
+
 def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias=None, relu=False, a_scale=None,
          a_rpg=0, c_scale=None, c_rpg=0, split_k=1, compute=None):
     """c (+)= alpha * op(a) @ op(b) (+ bias).  2-D operands, or 3-D with a leading batch axis; a 2-D `c`
@@ -310,6 +340,7 @@ class PackedCell:
         self.rnn_type, self.H, self.Ks = rnn_type, H, list(Ks)
         self.geom = rnn_geometry(rnn_type, H, Ks)
         self.Wp = torch.empty(self.geom.wp_floats, device=device, dtype=torch.float32)
+        self.Wp16 = None                                         # bf16 image, kept fresh by pack() under mixed precision
 
     def pack(self, weights):
         n = len(weights)
@@ -322,7 +353,14 @@ class PackedCell:
             _dev(w, name="weight")
             assert w.shape[0] == k and w.stride(1) == 1
         check(lib().asr_rnn_pack(rnn_type_id(self.rnn_type), self.H, n, Wp, ld, K, rec, _p(self.Wp), _stream()))
+        if mixed_precision():
+            if self.Wp16 is None:
+                self.Wp16 = torch.empty(self.Wp.numel(), device=self.Wp.device, dtype=torch.bfloat16)
+            f32_to_bf16(self.Wp, self.Wp16)
         return self
+
+    def wp16_ptr(self):
+        return self.Wp16.data_ptr() if (self.Wp16 is not None and mixed_precision()) else None
 
 
 def _arr2(vals, ctype=C.c_void_p):
@@ -339,6 +377,8 @@ def make_rnn_seq(rnn_type, B, T, H, dirs, mask, y, y_cols):
     s.reverse = (C.c_int * 2)(*([int(d.get("reverse", False)) for d in dirs] + [0] * (2 - len(dirs))))
     s.pre = _arr2([d["pre"] for d in dirs])
     s.Wp = _arr2([d["cell"].Wp for d in dirs])
+    s.Wp16 = _arr2([d["cell"].wp16_ptr() for d in dirs])
+    s.U16 = _arr2([bf16_twin(d.get("U")) for d in dirs])
     s.U = _arr2([d.get("U") for d in dirs])
     s.ldu = _arr2([d["U"].stride(0) if d.get("U") is not None else 0 for d in dirs], C.c_long)
     s.bias_rec = _arr2([d.get("bias_rec") for d in dirs])
@@ -413,6 +453,7 @@ def back_src(D, W, rnn_type, H, kind, drop=None):
     drop: (rate, stream, ld, off) of the consumer's input dropout or None."""
     s = _lib.RnnBackSrc()
     s.D, s.ldd, s.W, s.ldw = D.data_ptr(), D.stride(0), W.data_ptr(), W.stride(0)
+    s.W16 = bf16_twin(W)
     if rnn_type == "gru":
         if kind == "rec":
             s.nseg = 2

@@ -44,6 +44,15 @@ class ParamStore:
         self.adam_v = torch.zeros(off, device=device, dtype=torch.float32)
         self.p = {n: self._view(self.flat, n) for n in self.shapes}
         self.g = {n: self._view(self.grad, n) for n in self.shapes}
+        self.flat16 = None          # bf16 image of `flat` (mixed precision), refreshed once per optimizer step
+
+    def refresh_bf16(self):
+        """Bring the bf16 image of the parameters up to date (one pass over the flat buffer) and make it known to ops."""
+        from . import ops
+        if self.flat16 is None:
+            self.flat16 = torch.empty(self.numel, device=self.flat.device, dtype=torch.bfloat16)
+            ops.register_bf16_mirror(self.flat, self.flat16)
+        ops.f32_to_bf16(self.flat, self.flat16)
 
     def _view(self, buf, n):
         o = self.offsets[n]

@@ -27,6 +27,11 @@ class HipBiRNN:
             b_in = b[0] if rnn_type == "gru" else b
             pre = gpu((x.double() @ W.double() + b_in.double()).float())
             Ug = gpu(U)
+            if ops.mixed_precision():            # bf16 image of the recurrent kernel for the wide step kernels
+                img = torch.empty(Ug.numel(), device="cuda", dtype=torch.bfloat16)
+                ops.register_bf16_mirror(Ug.view(-1), img)
+                ops.f32_to_bf16(Ug.view(-1), img)
+                self._images = getattr(self, "_images", []) + [img]
             cell = ops.PackedCell(rnn_type, H, [H]).pack([(Ug, True)])
             dd = dict(pre=pre, cell=cell, U=Ug, reverse=(d == 1), hseq=torch.zeros(B, T, H, device="cuda"),
                       saved=torch.zeros(B, T, ns * H, device="cuda"))

@@ -146,3 +146,35 @@ def test_persistent_backward_matches_step_kernels(rt, B, T, D, H, masked):
         assert_close(res[1][1][d], res[0][1][d], 2e-5, "ds")
         for k in res[0][0][d]:
             assert_close(res[1][0][d][k], res[0][0][d][k], 2e-5, k)
+
+
+@pytest.mark.parametrize("rt,B,T,D,H", [("lstm", 40, 5, 8, 512), ("gru", 64, 4, 6, 516)])
+def test_wide_step_kernels_mixed_precision(rt, B, T, D, H):
+    """--mixed-precision on the wide step kernels (H >= 512, several batch tiles): bf16 weight images and bf16-rounded
+    states on the bf16 MFMA, f32 accumulation.  Outputs and gradients stay within bf16 rounding of the f32 kernels
+    and are not identical to them (the images are in use)."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    fwd, bwd = make_params(rt, D, H, g, 0.05)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = torch.randn(B, T, generator=g) > -0.5
+    dy = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64)
+    nst = 2 if rt == "lstm" else 1
+    res = {}
+    for mode in (False, True):
+        ops.set_mixed_precision(mode)
+        try:
+            hip = HipBiRNN(rt, x, mask, fwd, bwd, None)
+            y, _ = hip.forward(persistent=False)
+            y = y.clone()
+            grads = hip.backward(dy, [None] * (2 * nst), persistent=False)
+            res[mode] = (y, {f"{i}/{k}": v.clone() for i, r in enumerate(grads) for k, v in r.items()})
+        finally:
+            ops.set_mixed_precision(False)
+    y0, y1 = res[False][0], res[True][0]
+    d = float((y0 - y1).abs().max())
+    assert 0.0 < d < 2e-2 * max(1.0, float(y0.abs().max())), d
+    for k in res[False][1]:
+        a, b = res[False][1][k], res[True][1][k]
+        scale = max(1e-3, float(a.abs().max()))
+        assert float((a - b).abs().max()) < 5e-2 * scale, (k, float((a - b).abs().max()), scale)
