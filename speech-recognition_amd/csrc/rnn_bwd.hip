@@ -226,6 +226,7 @@ __device__ __forceinline__ void back_partial_wide(const BackSrc& s, int b0, int 
   if (s.D == nullptr) return;
   for (int g = 0; g < s.nseg; ++g) {
     const int len = s.len[g], nb = (len + 15) >> 4;
+    // two column blocks in flight per wave: with 8 (bf16) / 4 (f32) las_large ran 226 / 317 ms per step against 186 / 309
     for (int j0 = wave; j0 < nb; j0 += BW_NW * 2) {
       float4 av[2][NT], bv[WBF ? 1 : 2][NU];
       uint2 bh[2][NU];
