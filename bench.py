@@ -47,8 +47,8 @@ WORKLOADS = {
                            "SpecAugment+delta on GPU, teacher forcing on, fwd+bwd+Adam(lr 2e-4)", precision="bf16"),
 }
 PRECISION_TEXT = {"f32": "f32 throughout",
-                  "bf16": "mixed precision: dense contractions (gemm) with bf16 operands on the bf16 MFMA, f32 accumulation; "
-                          "recurrent cells, convolutions, softmax/CTC, BN, Adam and all storage f32"}
+                  "bf16": "mixed precision: dense contractions (gemm) and the wide (H >= 512) recurrent step kernels with bf16 operands on "
+                          "the bf16 MFMA, f32 accumulation; other recurrent cells, convolutions, softmax/CTC, BN, Adam and all storage f32"}
 
 
 def load_yaml(name):

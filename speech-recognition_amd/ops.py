@@ -246,8 +246,10 @@ _compute = {"gemm": 0}
 def set_mixed_precision(on: bool):
     """train.py:62-66 --mixed-precision on MI355X: every dense contraction that goes through `gemm` (input and
     output projections, attention keys, vocabulary layer, and their gradients) rounds its operands to bf16 on the
-    way into the bf16 MFMA; storage, accumulation, epilogues, recurrent cells, convolutions, softmax / CTC,
-    batch norm and Adam stay f32 (f32 master weights).  A process-wide switch, like the Keras global policy."""
+    way into the bf16 MFMA, and the wide (H >= 512) recurrent step kernels read bf16 images of their weights
+    (ParamStore.refresh_bf16 / PackedCell.pack); storage, accumulation, epilogues, gate math, the other recurrent
+    kernels, convolutions, softmax / CTC, batch norm and Adam stay f32 (f32 master weights).  A process-wide switch,
+    like the Keras global policy."""
     _compute["gemm"] = 1 if on else 0
 
 
