@@ -361,6 +361,165 @@ __global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_wide_kernel(Bwd2Args 
   }
 }
 
+// ------------------------------------------------------------------------------------------ staged backward step
+// The wide kernel above loads every MFMA operand straight from global memory, one float4 per lane: a wave instruction
+// then touches 16 different rows (64-byte pieces), and a wave owning 16 column blocks of a 4096-column contraction
+// makes 8 dependent round trips per step.  Here the workgroup (32 units x 16 rows, 16 waves) walks the column axis in
+// chunks of KC columns staged through LDS like a GEMM: coalesced 16-byte loads (a wave reads whole 1-KB row pieces),
+// the next chunk prefetched into registers while the current one is multiplied, fragments read from padded LDS rows.
+template <int WBF>
+struct Staged {
+  static constexpr int CW = WBF ? 32 : 16;          // columns per wave per chunk (one bf16 MFMA / four f32 MFMA steps)
+  static constexpr int KC = BW_NW * CW;             // 512 / 256
+  static constexpr int A_LD = KC + 4;               // floats: rows 4 banks apart -> conflict-free b128 reads
+  static constexpr int B_LD = WBF ? KC + 8 : KC + 4;   // bf16 elements / floats
+  static constexpr int A_FLOATS = 16 * A_LD;
+  static constexpr int B_BYTES = 32 * B_LD * (WBF ? 2 : 4);
+  static constexpr int A_V = 16 * KC / 4 / (64 * BW_NW);      // float4 per thread per chunk (2 / 1)
+  static constexpr int B_V = WBF ? 32 * KC / 8 / (64 * BW_NW) : 32 * KC / 4 / (64 * BW_NW);   // 16-byte pieces per thread (2 / 2)
+  static size_t smem_bytes(bool two) { return sizeof(float) * (two ? 2 : 1) * BW_NW * 2 * 256 + sizeof(float) * A_FLOATS + B_BYTES; }
+};
+
+template <int WBF>
+__device__ __forceinline__ void back_partial_staged(const BackSrc& s, int b0, int unit0, int B, int n_units, float* As, void* Bsv,
+                                                    f32x4 (&acc)[2]) {
+  using G = Staged<WBF>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (s.D == nullptr) return;
+  float* Bf = static_cast<float*>(Bsv);
+  unsigned short* Bh = static_cast<unsigned short*>(Bsv);
+  float4 ra[G::A_V];
+  uint4 rb[G::B_V];
+  auto gload = [&](int g, int k0) {
+    const int len = s.len[g];
+#pragma unroll
+    for (int i = 0; i < G::A_V; ++i) {
+      const int idx = tid + 64 * BW_NW * i, row = idx / (G::KC / 4), c = k0 + 4 * (idx % (G::KC / 4));
+      ra[i] = (b0 + row < B && c < len) ? *reinterpret_cast<const float4*>(s.D + (long)(b0 + row) * s.ldd + s.d_col0[g] + c)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < G::B_V; ++i) {
+      const int idx = tid + 64 * BW_NW * i;
+      if (WBF) {
+        const int un = idx / (G::KC / 8), c = k0 + 8 * (idx % (G::KC / 8));
+        rb[i] = (unit0 + un < n_units && c < len) ? *reinterpret_cast<const uint4*>(s.W16 + (long)(unit0 + un) * s.ldw + s.w_col0[g] + c)
+                                                  : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const int un = idx / (G::KC / 4), c = k0 + 4 * (idx % (G::KC / 4));
+        rb[i] = (unit0 + un < n_units && c < len) ? *reinterpret_cast<const uint4*>(s.W + (long)(unit0 + un) * s.ldw + s.w_col0[g] + c)
+                                                  : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::A_V; ++i) {
+      const int idx = tid + 64 * BW_NW * i, row = idx / (G::KC / 4), c4 = idx % (G::KC / 4);
+      *reinterpret_cast<float4*>(As + row * G::A_LD + 4 * c4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < G::B_V; ++i) {
+      const int idx = tid + 64 * BW_NW * i;
+      if (WBF) {
+        const int un = idx / (G::KC / 8), c8 = idx % (G::KC / 8);
+        *reinterpret_cast<uint4*>(Bh + un * G::B_LD + 8 * c8) = rb[i];
+      } else {
+        const int un = idx / (G::KC / 4), c4 = idx % (G::KC / 4);
+        *reinterpret_cast<uint4*>(Bf + un * G::B_LD + 4 * c4) = rb[i];
+      }
+    }
+  };
+  // chunk list: the segments one after the other, each in steps of KC columns
+  int g = 0, k0 = 0;
+  gload(g, k0);
+  for (;;) {
+    lstore();
+    __syncthreads();
+    int gn = g, kn = k0 + G::KC;
+    if (kn >= s.len[g]) { gn = g + 1; kn = 0; }
+    const bool more = gn < s.nseg;
+    if (more) gload(gn, kn);
+    if (WBF) {
+      const float* ar = As + li * G::A_LD + 32 * wave + 8 * lq;
+      const float4 x0 = *reinterpret_cast<const float4*>(ar), x1 = *reinterpret_cast<const float4*>(ar + 4);
+      bf16x8 a8;
+      a8[0] = (__bf16)x0.x; a8[1] = (__bf16)x0.y; a8[2] = (__bf16)x0.z; a8[3] = (__bf16)x0.w;
+      a8[4] = (__bf16)x1.x; a8[5] = (__bf16)x1.y; a8[6] = (__bf16)x1.z; a8[7] = (__bf16)x1.w;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(Bh + (16 * u + li) * G::B_LD + 32 * wave + 8 * lq);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, raw), acc[u], 0, 0, 0);
+      }
+    } else {
+      const float4 x = *reinterpret_cast<const float4*>(As + li * G::A_LD + 16 * wave + 4 * lq);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float4 w = *reinterpret_cast<const float4*>(Bf + (16 * u + li) * G::B_LD + 16 * wave + 4 * lq);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, w.x, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, w.y, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, w.z, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, w.w, acc[u], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (!more) break;
+    g = gn; k0 = kn;
+  }
+}
+
+template <int CELL, int WBF>
+__global__ __launch_bounds__(64 * BW_NW) void rnn_step_bwd_staged_kernel(Bwd2Args a) {
+  using G = Staged<WBF>;
+  extern __shared__ __attribute__((aligned(16))) float bw_smem[];   // [sources][BW_NW][2 tiles][256] slabs, then the A and B chunks
+  const Bwd2Dir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int unit0 = blockIdx.x * 32, b0 = blockIdx.y * 16;
+  const int B = a.B, H = d.n_units;
+  const bool linear = d.out != nullptr;
+  bool two = false;                                              // the launch sizes LDS for the widest direction
+  for (int z = 0; z < (int)gridDim.z; ++z) two = two || a.d[z].src[1].D != nullptr;
+  constexpr int SLAB = 2 * 256;
+  float* As = bw_smem + (two ? 2 : 1) * BW_NW * SLAB;
+  void* Bs = As + G::A_FLOATS;
+
+  // pair p (threads 0..511) -> (unit tile u, row, unit): p = (u * 16 + row) * 16 + un  (= the slab layout)
+  const int p = tid, tile = p >> 8, row = (p >> 4) & 15, un = p & 15;
+  const int b = b0 + row, j = unit0 + 16 * tile + un;
+  const bool owner = p < 512 && b < B && j < H;
+  BwdOperands op;
+  if (owner) load_bwd_operands<CELL>(d, b, j, H, linear, op);
+
+  f32x4 acc[2];
+  back_partial_staged<WBF>(d.src[0], b0, unit0, B, H, As, Bs, acc);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bw_smem[(long)wave * SLAB + u * 256 + (lq * 4 + r) * 16 + li] = acc[u][r];
+  const bool mine = d.src[1].D != nullptr;
+  if (two) {                                                     // (uniform over the launch: every workgroup takes the barriers inside)
+    back_partial_staged<WBF>(d.src[1], b0, unit0, B, H, As, Bs, acc);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bw_smem[(long)(BW_NW + wave) * SLAB + u * 256 + (lq * 4 + r) * 16 + li] = acc[u][r];
+  }
+  __syncthreads();
+  if (!owner) return;
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < BW_NW; ++w) sa += bw_smem[(long)w * SLAB + p];
+  if (mine) {
+#pragma unroll
+    for (int w = 0; w < BW_NW; ++w) sb += bw_smem[(long)(BW_NW + w) * SLAB + p];
+  }
+  bwd_finish<CELL>(d, a.seed, b, j, H, linear, op, sa, sb);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static inline int cell_nsaved(int cell) { return cell == CELL_RNN ? 1 : 4; }
 
@@ -442,6 +601,44 @@ static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st)
   if (wide && nu >= min_h && a.B > 16 && (cols >= 2048 || min_h < 512)) {
     bool two = false;
     for (int i = 0; i < ndir; ++i) two = two || a.d[i].src[1].D != nullptr;
+    static const int staged = getenv("ASR_RNN_STAGED") ? atoi(getenv("ASR_RNN_STAGED")) : 1;
+    bool bf = true, ok = staged != 0;
+    for (int i = 0; i < ndir; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const BackSrc& sc = a.d[i].src[k];
+        if (!sc.D) continue;
+        bf = bf && sc.W16 != nullptr;
+        ok = ok && sc.vec;
+        for (int g = 0; g < sc.nseg; ++g) ok = ok && sc.len[g] % 4 == 0;
+      }
+    for (int i = 0; i < ndir && ok && bf; ++i)
+      for (int k = 0; k < 2; ++k) {
+        const BackSrc& sc = a.d[i].src[k];
+        if (!sc.D) continue;
+        ok = ok && sc.ldw % 8 == 0 && (((uintptr_t)sc.W16) & 15) == 0;
+        for (int g = 0; g < sc.nseg; ++g) ok = ok && sc.w_col0[g] % 8 == 0 && sc.len[g] % 8 == 0;
+      }
+    if (ok) {
+      dim3 grid((unsigned)asr_cdiv(nu, 32), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
+      auto go = [&](auto kern, size_t smem) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * BW_NW), smem, st, a);
+      };
+      if (bf) {
+        const size_t smem = Staged<1>::smem_bytes(two);
+        if (rnn_type == CELL_LSTM) go(rnn_step_bwd_staged_kernel<CELL_LSTM, 1>, smem);
+        else if (rnn_type == CELL_GRU) go(rnn_step_bwd_staged_kernel<CELL_GRU, 1>, smem);
+        else go(rnn_step_bwd_staged_kernel<CELL_RNN, 1>, smem);
+      } else {
+        const size_t smem = Staged<0>::smem_bytes(two);
+        if (rnn_type == CELL_LSTM) go(rnn_step_bwd_staged_kernel<CELL_LSTM, 0>, smem);
+        else if (rnn_type == CELL_GRU) go(rnn_step_bwd_staged_kernel<CELL_GRU, 0>, smem);
+        else go(rnn_step_bwd_staged_kernel<CELL_RNN, 0>, smem);
+      }
+      ASR_LAUNCH_CHECK();
+      return ASR_OK;
+    }
     launch_bwd_wide<1, 2>(rnn_type, a, ndir, nu, two, st);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
