@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
 // Occupancy matters as much as traffic - measured on las_large (ms per training step, narrow 255.3):
 //   NT,NQ,NW = 4,2,4: 276   2,2,4: 245.6   2,2,8: 232.2   2,2,16: 232.2   1,2,8: 237.9   4,2,16: 238.3   1,4,16: 227.4
 //   2,4,16: 225.5 (chosen: forward step 36.9 -> 23.6 us).  Summing the waves' partials with LDS atomics instead of a
-//   slab per wave was far slower (319).
+//   slab per wave was far slower (319).  An LDS-staged variant in the style of rnn_step_bwd_staged_kernel (8 waves, one
+//   output tile each over the whole K axis, activations staged once, no cross-wave sum) was slower too (161.5 -> 191 ms
+//   mixed): with the weights already in fragment order the loads were never the problem here, and 8 waves per CU
+//   stream them with too little in flight.
 #define WD_CH 2
 
 // WBF = 1 (mixed precision): the weights come from their bf16 image and the inputs are rounded to bf16 in registers; one
