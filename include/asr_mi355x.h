@@ -358,6 +358,14 @@ long asr_rnn_persist_bwd_ws_floats(int B, int H, int ndir);
 int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
 
+/* The same two steps with the two streamed operands given as bf16 images (asr_f32_to_bf16 of Kq and enc, made once per
+ * training step): --mixed-precision.  The streams are what these kernels move, so the images halve their time; every
+ * product and sum stays f32.  Needs Hd % 8 == 0, D % 8 == 0, 16-byte aligned h / dctx rows. */
+int asr_attn_step_fwd_bf16(const float* h, long ldh, const void* Kq16, const float* s0, const uint8_t* mask, const void* enc16, int B,
+                           int T, int Hd, int D, float* e, float* p, float* ctx, long ldctx, void* stream);
+int asr_attn_step_bwd_bf16(const float* dctx, long lddctx, const float* p, const void* Kq16, const void* enc16, int B, int T, int Hd,
+                           int D, float* dp, float* ds, float* dh, long lddh, int accumulate, void* stream);
+
 /* The same two attention steps as ONE launch each (asr_attn_step_fwd / asr_attn_step_bwd are two): the T axis
  * is cut into chunks, every (batch row, chunk) workgroup publishes chunk-local softmax statistics and partial
  * sums, and the last one to arrive at an agent-scope ticket combines them.  Results equal to fp32 rounding

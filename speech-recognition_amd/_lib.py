@@ -154,6 +154,8 @@ SIGNATURES = {
                                 C.POINTER(RowDrop), _P]),
     "asr_argmax_rows": (C.c_int, [_P, c_long, C.c_int, C.c_int, _P, _P]),
     "asr_attn_step_fwd": (C.c_int, [_P, c_long, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long, _P]),
+    "asr_attn_step_fwd_bf16": (C.c_int, [_P, c_long, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long, _P]),
+    "asr_attn_step_bwd_bf16": (C.c_int, [_P, c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long, C.c_int, _P]),
     "asr_attn_step_bwd": (C.c_int, [_P, c_long, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, c_long,
                                     C.c_int, _P]),
     "asr_softmax_xent": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),

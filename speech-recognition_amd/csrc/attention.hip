@@ -164,3 +164,132 @@ extern "C" int asr_attn_step_bwd(const float* dctx, long lddctx, const float* p,
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
+
+// ------------------------------------------------------------------------------------------ bf16 streams (mixed precision)
+// The same two-launch steps reading bf16 images of Kq and enc (asr_f32_to_bf16 once per training step): the streams are
+// what these kernels move (LAS-large: 392 MB per decoder step), so the images halve their time; products and sums stay f32.
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+__global__ __launch_bounds__(256) void attn_rowdot16_kernel(const float* v, long ldv, const unsigned short* M, const float* s0, const uint8_t* mask,
+                                                            int T, int K, float* out) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* vb = v + (long)b * ldv;
+  const int t0 = blockIdx.x * (4 * ATT_RPW) + w * ATT_RPW;
+  float s[ATT_RPW];
+#pragma unroll
+  for (int r = 0; r < ATT_RPW; ++r) s[r] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {                      // K % 8 == 0: eight bf16 = 16 bytes per lane
+    const float4 h0 = *reinterpret_cast<const float4*>(vb + k), h1 = *reinterpret_cast<const float4*>(vb + k + 4);
+    uint4 kv[ATT_RPW];
+#pragma unroll
+    for (int r = 0; r < ATT_RPW; ++r)
+      kv[r] = (t0 + r < T) ? *reinterpret_cast<const uint4*>(M + ((long)b * T + t0 + r) * K + k) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < ATT_RPW; ++r) {
+      s[r] += h0.x * __uint_as_float(kv[r].x << 16) + h0.y * __uint_as_float(kv[r].x & 0xffff0000u) +
+              h0.z * __uint_as_float(kv[r].y << 16) + h0.w * __uint_as_float(kv[r].y & 0xffff0000u) +
+              h1.x * __uint_as_float(kv[r].z << 16) + h1.y * __uint_as_float(kv[r].z & 0xffff0000u) +
+              h1.z * __uint_as_float(kv[r].w << 16) + h1.w * __uint_as_float(kv[r].w & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ATT_RPW; ++r) {
+    const float tot = wave_sum(s[r]);
+    const int t = t0 + r;
+    if (lane == 0 && t < T) {
+      float val = tot + (s0 ? s0[(long)b * T + t] : 0.f);
+      if (mask) val -= 1e9f * (1.0f - (mask[(long)b * T + t] ? 1.0f : 0.0f));
+      out[(long)b * T + t] = val;
+    }
+  }
+}
+
+__device__ __forceinline__ float weighted_colsum16(const float* wgt, const unsigned short* Xb, int T, int D, int c, int w) {
+  float acc = 0.f;
+  if (c >= D) return 0.f;
+  for (int t0 = w; t0 < T; t0 += 4 * ATT_UNR) {
+    unsigned short x[ATT_UNR];
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) { const int t = t0 + 4 * i; x[i] = t < T ? Xb[(long)t * D + c] : (unsigned short)0; }
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) { const int t = t0 + 4 * i; if (t < T) acc = fmaf(wgt[t], bf2f(x[i]), acc); }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void attn_softmax_ctx16_kernel(const float* e, const unsigned short* enc, int T, int D, float* p_out, float* ctx,
+                                                                 long ldctx) {
+  extern __shared__ float sm[];
+  float* p = sm;
+  float* part = sm + T;
+  float* red = part + 256;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += 256) { const float v = e[(long)b * T + t]; p[t] = v; mx = fmaxf(mx, v); }
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { const float v = expf(p[t] - mx); p[t] = v; s += v; }
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+  __syncthreads();
+  if (blockIdx.x == 0 && p_out)
+    for (int t = threadIdx.x; t < T; t += 256) p_out[(long)b * T + t] = p[t] * inv;
+  part[w * 64 + (threadIdx.x & 63)] = weighted_colsum16(p, enc + (long)b * T * D, T, D, c, w);
+  __syncthreads();
+  if (w == 0 && c < D) ctx[(long)b * ldctx + c] = (part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x]) * inv;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dh16_kernel(const float* p, const float* dp, const unsigned short* Kq, int T, int Hd, float* ds_out,
+                                                            float* dh, long lddh, int accumulate) {
+  extern __shared__ float sm[];
+  float* ds = sm;
+  float* part = sm + T;
+  float* red = part + 256;
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float dot = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) dot = fmaf(p[(long)b * T + t], dp[(long)b * T + t], dot);
+  dot = block_sum(dot, red);
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = p[(long)b * T + t] * (dp[(long)b * T + t] - dot);
+    ds[t] = v;
+    if (blockIdx.x == 0 && ds_out) ds_out[(long)b * T + t] = v;
+  }
+  __syncthreads();
+  part[w * 64 + (threadIdx.x & 63)] = weighted_colsum16(ds, Kq + (long)b * T * Hd, T, Hd, c, w);
+  __syncthreads();
+  if (w == 0 && c < Hd) {
+    const float v = part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
+    float* o = dh + (long)b * lddh + c;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+extern "C" int asr_attn_step_fwd_bf16(const float* h, long ldh, const void* Kq16, const float* s0, const uint8_t* mask, const void* enc16, int B,
+                                      int T, int Hd, int D, float* e, float* p, float* ctx, long ldctx, void* stream) {
+  ASR_CHECK(h && Kq16 && mask && enc16 && e && p && ctx, ASR_ERR_ARG, "asr_attn_step_fwd_bf16: null argument");
+  ASR_CHECK(B > 0 && T > 0 && Hd > 0 && D > 0 && Hd % 8 == 0 && ldh % 4 == 0 && attn_smem(T) <= 64 * 1024, ASR_ERR_SHAPE,
+            "asr_attn_step_fwd_bf16: bad shape (Hd %% 8, ldh %% 4 required)");
+  ASR_CHECK(((((uintptr_t)h) | ((uintptr_t)Kq16)) & 15) == 0, ASR_ERR_ARG, "asr_attn_step_fwd_bf16: h and Kq16 must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_rowdot16_kernel, dim3((unsigned)asr_cdiv(T, 4 * ATT_RPW), (unsigned)B), dim3(256), 0, st, h, ldh,
+                     static_cast<const unsigned short*>(Kq16), s0, mask, T, Hd, e);
+  hipLaunchKernelGGL(attn_softmax_ctx16_kernel, dim3((unsigned)asr_cdiv(D, 64), (unsigned)B), dim3(256), attn_smem(T), st, (const float*)e,
+                     static_cast<const unsigned short*>(enc16), T, D, p, ctx, ldctx);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_attn_step_bwd_bf16(const float* dctx, long lddctx, const float* p, const void* Kq16, const void* enc16, int B, int T, int Hd,
+                                      int D, float* dp, float* ds, float* dh, long lddh, int accumulate, void* stream) {
+  ASR_CHECK(dctx && p && Kq16 && enc16 && dp && ds && dh, ASR_ERR_ARG, "asr_attn_step_bwd_bf16: null argument");
+  ASR_CHECK(B > 0 && T > 0 && Hd > 0 && D > 0 && D % 8 == 0 && lddctx % 4 == 0 && attn_smem(T) <= 64 * 1024, ASR_ERR_SHAPE,
+            "asr_attn_step_bwd_bf16: bad shape (D %% 8, lddctx %% 4 required)");
+  ASR_CHECK(((((uintptr_t)dctx) | ((uintptr_t)enc16)) & 15) == 0, ASR_ERR_ARG, "asr_attn_step_bwd_bf16: dctx and enc16 must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_rowdot16_kernel, dim3((unsigned)asr_cdiv(T, 4 * ATT_RPW), (unsigned)B), dim3(256), 0, st, dctx, lddctx,
+                     static_cast<const unsigned short*>(enc16), (const float*)nullptr, (const uint8_t*)nullptr, T, D, dp);
+  hipLaunchKernelGGL(attn_bwd_dh16_kernel, dim3((unsigned)asr_cdiv(Hd, 64), (unsigned)B), dim3(256), attn_smem(T), st, p, (const float*)dp,
+                     static_cast<const unsigned short*>(Kq16), T, Hd, ds, dh, lddh, accumulate);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

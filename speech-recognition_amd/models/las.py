@@ -318,6 +318,16 @@ class LAS(ModelProto):
         ops.gemm(ws.enc, p[a + "key_weight/kernel"], ws.K, bias=p[a + "key_weight/bias"])
         ops.gemm(ws.K, p[a + "query_weight/kernel"], ws.Kq, trans_b=True)
         ops.gemm(ws.K, p[a + "query_weight/bias"].view(self.Hd, 1), ws.s0)
+        # mixed precision: the decoder steps stream Kq and enc once each per step - give them bf16 images (wide models only:
+        # on las_small the streams sit in L2 / Infinity Cache and the steps are latency-bound either way)
+        ws.attn_images = None
+        if ops.mixed_precision() and self.Hd % 8 == 0 and (2 * self.He) % 8 == 0 and self.Hd >= int(os.environ.get("ASR_ATTN_IMAGE_MIN_HD", "512")):
+            if getattr(ws, "Kq16", None) is None:
+                ws.Kq16 = torch.empty(ws.Kq.numel(), device=ws.Kq.device, dtype=torch.bfloat16)
+                ws.enc16 = torch.empty(ws.enc.numel(), device=ws.enc.device, dtype=torch.bfloat16)
+            ops.f32_to_bf16(ws.Kq.view(-1), ws.Kq16)
+            ops.f32_to_bf16(ws.enc.view(-1), ws.enc16)
+            ws.attn_images = (ws.Kq16, ws.enc16)
 
     def _drops(self, ws, i0, n, training, step_offset=0):
         """Row-dropout descriptors of the decoder sites for step-major rows [i0*B, (i0+n)*B)."""
@@ -370,7 +380,8 @@ class LAS(ModelProto):
         if ws.attn_fused is not None:      # one launch per step
             ops.attn_fused_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.attn_fused, ws.p[i], ws.ctx[i])
         else:
-            ops.attn_step_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.e, ws.p[i], ws.ctx[i])
+            ops.attn_step_fwd(ws.hin[i], ws.Kq.view(B, ws.T2, Hd), ws.s0, ws.mask, ws.enc.view(B, ws.T2, 2 * He), ws.e, ws.p[i], ws.ctx[i],
+                              images=getattr(ws, "attn_images", None))
         for j, cell in enumerate(self.dec_cells):
             h_in, c_in, h_out, c_out = self._cell_states(ws, j, i)
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"
@@ -537,7 +548,8 @@ class LAS(ModelProto):
             if ws.attn_fused is not None:
                 ops.attn_fused_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.attn_fused, ws.ds[i], ws.dh_attn, accumulate=False)
             else:
-                ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False)
+                ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False,
+                                  images=getattr(ws, "attn_images", None))
         # gradient wrt the decoder's initial states (= listener state projections)
         lin = _lib.RnnStepBwd()
         lin.n_units = Hd

@@ -617,16 +617,25 @@ def argmax_rows(x, out):
 
 
 # ----------------------------------------------------------------------------------------- attention / loss / optimizer
-def attn_step_fwd(h, Kq, s0, mask, enc, e, p, ctx):
+def attn_step_fwd(h, Kq, s0, mask, enc, e, p, ctx, images=None):
+    """images: (Kq16, enc16) bfloat16 copies of Kq / enc (mixed precision) or None."""
     B, T, Hd = Kq.shape
     D = enc.shape[2]
+    if images is not None:
+        check(lib().asr_attn_step_fwd_bf16(_p(h), h.stride(0), C.c_void_p(images[0].data_ptr()), _p(s0), _p(mask),
+                                           C.c_void_p(images[1].data_ptr()), B, T, Hd, D, _p(e), _p(p), _p(ctx), ctx.stride(0), _stream()))
+        return
     check(lib().asr_attn_step_fwd(_p(h), h.stride(0), _p(Kq), _p(s0), _p(mask), _p(enc), B, T, Hd, D, _p(e), _p(p), _p(ctx),
                                   ctx.stride(0), _stream()))
 
 
-def attn_step_bwd(dctx, p, Kq, enc, dp, ds, dh, accumulate):
+def attn_step_bwd(dctx, p, Kq, enc, dp, ds, dh, accumulate, images=None):
     B, T, Hd = Kq.shape
     D = enc.shape[2]
+    if images is not None:
+        check(lib().asr_attn_step_bwd_bf16(_p(dctx), dctx.stride(0), _p(p), C.c_void_p(images[0].data_ptr()), C.c_void_p(images[1].data_ptr()),
+                                           B, T, Hd, D, _p(dp), _p(ds), _p(dh), dh.stride(0), int(accumulate), _stream()))
+        return
     check(lib().asr_attn_step_bwd(_p(dctx), dctx.stride(0), _p(p), _p(Kq), _p(enc), B, T, Hd, D, _p(dp), _p(ds), _p(dh),
                                   dh.stride(0), int(accumulate), _stream()))
 

@@ -192,6 +192,38 @@ def test_attention_step_forward_backward(B, T, Hd, D):
     assert_close(dh - 1.0, gh, 1e-4, "dh through the scores")
 
 
+@pytest.mark.parametrize("B,T,Hd,D", [(5, 13, 128, 128), (7, 61, 1024, 2048), (3, 111, 16, 32)])
+def test_attention_step_with_bf16_images(B, T, Hd, D):
+    """--mixed-precision: Kq and enc are streamed from bf16 images; products and sums in f32.  The results equal the
+    float64 attention on the ROUNDED Kq / enc to f32 accuracy."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * T + Hd + 7)
+    h = torch.randn(B, Hd, generator=g) * 0.3
+    Kq = torch.randn(B, T, Hd, generator=g) * (1.0 / np.sqrt(Hd))
+    enc = torch.randn(B, T, D, generator=g)
+    s0 = torch.randn(B, T, generator=g) * 0.1
+    mask = torch.randn(B, T, generator=g) > -0.5
+    mask[:, 0] = True
+    R = torch.randn(B, D, generator=g)
+    Kq16, enc16 = Kq.bfloat16(), enc.bfloat16()
+    Kr, er = Kq16.double(), enc16.double()
+    e_ref = torch.einsum("bh,bth->bt", h.double(), Kr) + s0.double() - 1e9 * (1.0 - mask.double())
+    p_ref = torch.softmax(e_ref, dim=1)
+    ctx_ref = torch.einsum("bt,btd->bd", p_ref, er)
+    dp_ref = torch.einsum("bd,btd->bt", R.double(), er)
+    ds_ref = p_ref * (dp_ref - (p_ref * dp_ref).sum(1, keepdim=True))
+    dh_ref = torch.einsum("bt,bth->bh", ds_ref, Kr)
+    e, pg, ctxg = torch.empty(B, T, device="cuda"), torch.empty(B, T, device="cuda"), torch.empty(B, D, device="cuda")
+    images = (Kq16.cuda().contiguous(), enc16.cuda().contiguous())
+    ops.attn_step_fwd(h.cuda(), Kq.cuda(), s0.cuda(), mask.to(torch.uint8).cuda(), enc.cuda(), e, pg, ctxg, images=images)
+    assert_close(pg, p_ref, 2e-5, "attention probs (bf16 streams)")
+    assert_close(ctxg, ctx_ref, 2e-5, "context (bf16 streams)")
+    dp, ds, dh = torch.empty(B, T, device="cuda"), torch.empty(B, T, device="cuda"), torch.zeros(B, Hd, device="cuda")
+    ops.attn_step_bwd(R.cuda(), pg, Kq.cuda(), enc.cuda(), dp, ds, dh, accumulate=False, images=images)
+    assert_close(ds, ds_ref, 1e-4, "score gradients (bf16 streams)")
+    assert_close(dh, dh_ref, 1e-4, "dh (bf16 streams)")
+
+
 @pytest.mark.parametrize("B,T,Hd,D", [(5, 13, 128, 128), (43, 33, 256, 512), (3, 111, 16, 32), (2, 2, 4, 4), (4, 249, 256, 512), (32, 499, 64, 128)])
 def test_fused_attention_step_matches_oracle_and_two_kernel_path(B, T, Hd, D):
     """One-launch attention steps (chunked softmax + last-arriver combine): same oracle, same tolerances as the
