@@ -325,7 +325,8 @@ typedef struct asr_rnn_seq {
   const float* bias_rec[2];                 /* GRU                                                   */
   const float* h0[2]; long h0_ld[2];        /* initial states (NULL = zeros)                         */
   const float* c0[2]; long c0_ld[2];
-  const float* rec_mult[2];                 /* reserved (recurrent dropout), must be NULL            */
+  const float* rec_mult[2];                 /* [B,H] recurrent-dropout multipliers (constant over time, deepspeech2.py:95-107) or NULL;
+                                               per-step kernels only - the persistent launches reject it */
   const uint8_t* mask;
   float* hseq[2]; float* cseq[2];
   float* y; long y_ld; int y_col[2];

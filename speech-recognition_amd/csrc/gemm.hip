@@ -118,7 +118,8 @@ static int asr_gemm_launch_f32(const GemmPlan& g) {
   const float* B = g.B;
   const bool a_fast = d->K > 0 && aligned16(A, d->lda, d->stride_a) && g.a_cols % 4 == 0 && g.a_cols >= 4;
   const bool b_fast = d->K > 0 && aligned16(B, d->ldb, d->stride_b) && g.b_cols % 4 == 0 && g.b_cols >= 4;
-  const bool s_fast = d->a_scale && (((uintptr_t)d->a_scale & 15) == 0) && d->stride_a_scale % 4 == 0 &&
+  // (rows-per-group 1 has no 32-bit reciprocal: ceil(2^32 / 1) wraps to 0 - it takes the plain loader)
+  const bool s_fast = d->a_scale && (((uintptr_t)d->a_scale & 15) == 0) && d->stride_a_scale % 4 == 0 && d->a_rpg > 1 &&
                       (long)g.a_rows * d->a_rpg < 4294967296L;
   if (a_fast && b_fast && !d->a_scale) {
     launch_l(g, FastLoader{A, d->lda, g.a_rows, g.a_cols}, FastLoader{B, d->ldb, g.b_rows, g.b_cols});

@@ -79,6 +79,7 @@ __global__ void rnn_pack_kernel(PackArgs a) {
 struct FwdSeg {
   const float* x; long ld; int K; int ks0; int vec;
   int drop; uint32_t drop_stream; float drop_rate; long drop_ld; int drop_off;
+  const float* mult; long mult_ld;      // optional multiplier table [B, K] on this segment (Keras recurrent dropout: constant over time)
 };
 struct FwdDir {
   FwdSeg seg[ASR_RNN_MAXSEG];
@@ -88,6 +89,7 @@ struct FwdDir {
   const float* pre; long pre_ld;
   const float* bias; const float* bias_rec;
   const float* h_prev; long h_prev_ld;
+  const float* hmult; long hmult_ld;    // recurrent-dropout multiplier of the owned (row, unit) pairs: the GRU z * h carry sees it too
   const float* c_prev; long c_prev_ld;
   const float* y_prev; long y_prev_ld;
   const uint8_t* mask; long mask_ld;
@@ -105,8 +107,10 @@ struct FwdArgs { FwdDir d[2]; int B, H; const uint32_t* seed; };
 // Gate math of one (batch row b, hidden unit j) pair from the pre-activations `pre` (+ biases), the recurrent
 // sums s[4] (slot order of the packed weights) and the previous state; writes h / c / y / saved.
 template <int CELL>
-__device__ __forceinline__ void cell_finish(const FwdDir& d, int H, int b, int j, bool m, float hp, float yp, float cp, const float* pre,
-                                            const float* br, const float* s) {
+__device__ __forceinline__ void cell_finish(const FwdDir& d, int H, int b, int j, bool m, float hp, float hpm, float yp, float cp,
+                                            const float* pre, const float* br, const float* s) {
+  // hpm = hp times the recurrent-dropout multiplier (= hp without recurrent dropout): [TF-sem] GRUCell rebinds h_tm1 to the
+  // masked value, so the z * h_tm1 carry sees the multiplier; the state carried through a masked step does not
   float hn, cn = 0.f;
   if (CELL == CELL_LSTM) {
     const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
@@ -124,7 +128,7 @@ __device__ __forceinline__ void cell_finish(const FwdDir& d, int H, int b, int j
     const float r = sigmoidf_(pre[1] + s[1] + br[1]);
     const float arh = s[3] + br[2];
     const float hh = tanhf_(pre[2] + s[2] + r * arh);
-    hn = z * hp + (1.f - z) * hh;
+    hn = z * hpm + (1.f - z) * hh;
     if (d.saved) {
       float* sv = d.saved + (long)b * d.saved_ld + j;
       sv[0] = z; sv[H] = r; sv[2L * H] = hh; sv[3L * H] = arh;
@@ -169,6 +173,8 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
     if (CELL == CELL_LSTM) cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
     if (CELL == CELL_GRU && d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
   }
+  float hpm = hp;
+  if (wave == 0 && live && d.hmult) hpm = hp * d.hmult[(long)b * d.hmult_ld + j];
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float4* wp = reinterpret_cast<const float4*>(d.Wp) + (long)q * d.KSt * 64 + lane;
@@ -213,6 +219,17 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
           av[i].w *= asr_drop_mult(key, idx + 3, thr, dscale);
         }
       }
+      if (sg.mult && rowok) {
+        const float* mr = sg.mult + (long)brow * sg.mult_ld;
+#pragma unroll
+        for (int i = 0; i < RNN_CH; ++i) {
+          const int k = 16 * (j0 + 4 * i) + 4 * lq;
+          if (k < sg.K) av[i].x *= mr[k];
+          if (k + 1 < sg.K) av[i].y *= mr[k + 1];
+          if (k + 2 < sg.K) av[i].z *= mr[k + 2];
+          if (k + 3 < sg.K) av[i].w *= mr[k + 3];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < RNN_CH; ++i) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc, 0, 0, 0);
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     s[g] = part[0][bi * 17 + g * 4 + u] + part[1][bi * 17 + g * 4 + u] + part[2][bi * 17 + g * 4 + u] + part[3][bi * 17 + g * 4 + u];
-  cell_finish<CELL>(d, H, b, j, m, hp, yp, cp, pre, br, s);
+  cell_finish<CELL>(d, H, b, j, m, hp, hpm, yp, cp, pre, br, s);
 }
 
 // ------------------------------------------------------------------------------------------ wide forward step
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(64 * NW) void rnn_step_fwd_wide_kernel(FwdArgs a) {
       for (int w = 0; w < NW; ++w) v += part[w][t][qi][bi * 17 + g * 4 + u];
       s4[g] = v;
     }
-    cell_finish<CELL>(d, H, b, j, m[r], hp[r], yp[r], cp[r], pre[r], br[r], s4);
+    cell_finish<CELL>(d, H, b, j, m[r], hp[r], hp[r], yp[r], cp[r], pre[r], br[r], s4);
   }
 }
 
@@ -482,7 +499,9 @@ static int launch_fwd(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) 
   // wide cells with several batch tiles: 16 units x 32 rows per workgroup (see rnn_step_fwd_wide_kernel); ASR_RNN_WIDE=0 turns it off
   static const int wide = getenv("ASR_RNN_WIDE") ? atoi(getenv("ASR_RNN_WIDE")) : 1;
   static const int min_h = getenv("ASR_RNN_WIDE_MIN_H") ? atoi(getenv("ASR_RNN_WIDE_MIN_H")) : 512;   // tests lower it
-  if (wide && a.H >= min_h && a.B > 16) {
+  bool mult = false;                                             // recurrent dropout: narrow kernel only
+  for (int i = 0; i < ndir; ++i) mult = mult || a.d[i].hmult != nullptr;
+  if (wide && !mult && a.H >= min_h && a.B > 16) {
     launch_fwd_wide<2, 4, 16>(rnn_type, a, ndir, st);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
@@ -524,7 +543,6 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
   asr_rnn_geometry(s->rnn_type, H, 1, K1, &g);
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_seq_fwd: null buffer (dir %d)", d);
-    ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_seq_fwd: recurrent dropout is not supported");
   }
   for (int step = 0; step < T; ++step) {
     FwdArgs a{};
@@ -551,6 +569,8 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
       }
       fd.seg[0].x = fd.h_prev; fd.seg[0].ld = fd.h_prev_ld; fd.seg[0].K = H; fd.seg[0].ks0 = 0;
       fd.seg[0].vec = (((uintptr_t)fd.h_prev & 15) == 0) && (fd.h_prev_ld % 4 == 0);
+      fd.seg[0].mult = s->rec_mult[d]; fd.seg[0].mult_ld = H;       // deepspeech2.py:95-107 recurrent_dropout: h_tm1 * mask[B,H]
+      fd.hmult = s->rec_mult[d]; fd.hmult_ld = H;
       fd.mask = s->mask ? s->mask + t : nullptr; fd.mask_ld = T;
       fd.h_out = hseq + (long)t * H; fd.h_out_ld = (long)T * H;
       fd.c_out = lstm ? cseq + (long)t * H : nullptr; fd.c_out_ld = (long)T * H;

@@ -47,6 +47,7 @@ struct Bwd2Dir {
   const float* c_prev; long c_prev_ld;
   const float* c_out; long c_out_ld;
   float* dslots; long dslots_ld;
+  const float* rmult; long rmult_ld;   // recurrent-dropout multiplier [B, n_units] of the state this step hands back (or NULL)
 };
 struct Bwd2Args { Bwd2Dir d[2]; int B; const uint32_t* seed; };
 
@@ -92,13 +93,14 @@ __device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit
 // Element-wise part of one backward step for the (batch row b, unit j) pair, from the two matrix-product sums.
 struct BwdOperands {
   bool m;
-  float carry, svv[4], cpv, cov, dcv, hpv, addAv, addBv, dirv;
+  float carry, svv[4], cpv, cov, dcv, hpv, addAv, addBv, dirv, rm;
 };
 
 template <int CELL>
 __device__ __forceinline__ void load_bwd_operands(const Bwd2Dir& d, int b, int j, int H, bool linear, BwdOperands& o) {
   constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
   o.m = true; o.carry = 0.f; o.cpv = 0.f; o.cov = 0.f; o.dcv = 0.f; o.hpv = 0.f; o.addAv = 0.f; o.addBv = 0.f; o.dirv = 0.f;
+  o.rm = d.rmult ? d.rmult[(long)b * d.rmult_ld + j] : 1.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) o.svv[g] = 0.f;
   if (d.addA) o.addAv = d.addA[(long)b * d.addA_ld + j];
@@ -124,7 +126,10 @@ __device__ __forceinline__ void bwd_finish(const Bwd2Dir& d, const uint32_t* see
                                            float sa, float sb) {
   constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
   const bool m = op.m;
-  const float carry = op.carry, cpv = op.cpv, cov = op.cov, dcv = op.dcv, hpv = op.hpv, addAv = op.addAv, addBv = op.addBv, dirv = op.dirv;
+  // recurrent dropout (rm != 1): the consumer read h * rm through its recurrent kernel, and the GRU carry is z * (h_prev * rm)
+  const float rm = op.rm;
+  sa *= rm;
+  const float carry = op.carry, cpv = op.cpv, cov = op.cov, dcv = op.dcv, hpv = op.hpv * rm, addAv = op.addAv, addBv = op.addBv, dirv = op.dirv;
   const float* svv = op.svv;
   struct { const uint32_t* seed; } a{seed};
   if (d.src[1].D != nullptr && d.src[1].drop_rate > 0.f) {
@@ -162,7 +167,7 @@ __device__ __forceinline__ void bwd_finish(const Bwd2Dir& d, const uint32_t* see
       ds[1] = dahh * arh * r * (1.f - r);
       ds[2] = dahh;
       ds[3] = dahh * r;
-      dir = dh * z;
+      dir = dh * z * rm;
     } else {
       const float hn = svv[0];
       ds[0] = dh * (1.f - hn * hn);
@@ -598,7 +603,9 @@ static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st)
       for (int g = 0; g < a.d[i].src[k].nseg; ++g) c += a.d[i].src[k].D ? a.d[i].src[k].len[g] : 0;
       cols = c > cols ? c : cols;
     }
-  if (wide && nu >= min_h && a.B > 16 && (cols >= 2048 || min_h < 512)) {
+  bool rmult = false;                                            // recurrent dropout: narrow kernel only
+  for (int i = 0; i < ndir; ++i) rmult = rmult || a.d[i].rmult != nullptr;
+  if (wide && !rmult && nu >= min_h && a.B > 16 && (cols >= 2048 || min_h < 512)) {
     bool two = false;
     for (int i = 0; i < ndir; ++i) two = two || a.d[i].src[1].D != nullptr;
     static const int staged = getenv("ASR_RNN_STAGED") ? atoi(getenv("ASR_RNN_STAGED")) : 1;
@@ -736,6 +743,7 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
       if (sb.n_units > 0) {
         int rc = fill_dir(&a.d[d], &sb, s->rnn_type, nullptr);
         if (rc) return rc;
+        a.d[d].rmult = s->rec_mult[d]; a.d[d].rmult_ld = H;
         any = true;
       } else {
         a.d[d] = Bwd2Dir{};   // n_units == 0: every thread of that direction exits as a non-owner

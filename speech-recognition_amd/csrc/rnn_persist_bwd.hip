@@ -244,6 +244,7 @@ extern "C" int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_g
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_seq_bwd_persist: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_seq_bwd_persist: null buffer (dir %d)", d);
+    ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_seq_bwd_persist: recurrent dropout is not supported");
     const long ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H;
     ASR_CHECK((((uintptr_t)s->U[d]) & 15) == 0 && ldu % 4 == 0, ASR_ERR_ARG, "asr_rnn_seq_bwd_persist: recurrent kernel must be 16-byte aligned");
     PBDir& p = a.d[d];

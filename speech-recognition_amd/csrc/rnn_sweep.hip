@@ -1,0 +1,334 @@
+// One-launch forward sweep of a whole (Bi)RNN layer on gfx950 (las.py:62-126 BiRNN, deepspeech2.py:109-119): all T
+// time steps of both directions in ONE kernel, the recurrent kernel resident in registers, h_t handed from
+// workgroup to workgroup through a small exchange buffer in global memory.
+//
+// Work split (same as the per-step kernel of rnn.hip, so the arithmetic and its order are identical): the workgroups
+// of a (direction, 16-row batch tile) GROUP each own NQ slices of 4 hidden units x all gates; per step a workgroup
+// multiplies the group's h_{t-1} [16 x H] with its [H x 16 NQ] slice of U on v_mfma_f32_16x16x4_f32 (K split over the
+// 4 waves, reduced through LDS), does the gate math of its 16 x 4 NQ (row, unit) pairs and publishes their h_t.
+//
+// Hand-off ("the data is the flag", cdna_hip_programming.md Guideline 16 R2, without a tag word): h values are always
+// finite, so a slot that holds the SENTINEL (a NaN bit pattern no arithmetic produces) has not been written yet.
+//   exchange buffer, per group: [4 slots][Q][16 rows][4 units] f32; step s publishes into slot s % 4;
+//   producer: ONE `global_store_dwordx4 ... sc1` per (row, 4-unit slice): a slice's 16 rows are two whole 128-B lines;
+//   consumer: every wave re-reads the 16-byte pieces it needs with `global_load_dwordx4 ... sc1` (L1 bypassed) until none
+//             of their 4 words is the sentinel - every word validates itself, so no ordering between words is assumed;
+//   re-arming: after publishing step s a workgroup overwrites ITS OWN slices of slot (s + 2) % 4 (which held h_{s-2})
+//             with the sentinel.  Having gathered all of h_{s-1} it knows that every workgroup has finished step s - 1
+//             and therefore consumed h_{s-2}.  The next publish (step s + 1) is issued only after the gather of step
+//             s + 1, whose `s_waitcnt vmcnt(0)` also retires that re-arming store; so by the time any consumer can look
+//             at slot (s + 2) % 4 for h_{s+2} (it must first have seen this workgroup's h_{s+1}) the sentinel - or the
+//             new value - is what memory holds.  Four slots instead of three keep that wait off the critical path.
+// Compared with {value, tag} granules this halves the bytes every step moves across the fabric (16 KB instead of 32 KB
+// per workgroup at H = 256) and the number of load instructions per gather.
+// The buffer is filled with the sentinel before every launch; every spin is bounded: on time-out the workgroup raises
+// the error word (and the caller's sticky error flag) and leaves, its peers follow one time-out later.
+// Residency: all workgroups of a group must be resident together - 256-thread workgroups with < 20 KB of LDS, several
+// fit per CU, so a grid of <= 256 is co-resident even when another stream (RCCL) occupies part of the chip.
+#include <stdlib.h>
+
+#include "common.h"
+
+#define CELL_LSTM 0
+#define CELL_GRU 1
+#define CELL_RNN 2
+#define SW_MAXB 4                  // K blocks per wave held in registers: H <= 16 * 4 * SW_MAXB = 256
+#define SW_SLOTS 4
+#define SW_SENT 0x7FC0DEADu        // quiet NaN with a payload: never the result of an arithmetic instruction
+
+struct SwDir {
+  const float* pre; const float* Wp; const float* bias_rec;
+  const float* h0; long h0_ld; const float* c0; long c0_ld;
+  float* hseq; float* cseq; float* saved;
+  int reverse, y_col;
+};
+struct SwArgs {
+  SwDir d[2];
+  int B, T, H, KB;
+  const uint8_t* mask;
+  float* y; long y_ld;
+  float* xbuf;          // [groups][SW_SLOTS][Q][16 rows][4 units]
+  unsigned* err;        // per-launch error word (zeroed by the launch)
+  float* err_flag;      // caller's sticky flag (set to 1.0f on time-out, never cleared here) or NULL
+  int spin_limit;
+};
+
+static int g_spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
+extern "C" void asr_rnn_sweep_set_spin_limit(int polls) { g_spin_limit = polls; }
+extern "C" int asr_rnn_sweep_spin_limit(void) { return g_spin_limit; }
+
+__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero_words[threadIdx.x] = 0u;
+}
+
+template <int CELL, int NQ>
+__global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
+  __shared__ float part[2][4][NQ][16 * 17];
+  __shared__ int abort_flag;
+  const SwDir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int q0 = blockIdx.x * NQ, b0 = blockIdx.y * 16, Q = gridDim.x * NQ;
+  const int B = a.B, T = a.T, H = a.H;
+  const int group = blockIdx.z * gridDim.y + blockIdx.y;
+  const long slot_floats = (long)Q * 64;                                  // one slot: [Q][16][4]
+  float* xb = a.xbuf + (long)group * SW_SLOTS * slot_floats;
+  constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
+  constexpr int NS = CELL == CELL_RNN ? 1 : 4;
+
+  // this wave's share of the packed recurrent kernel stays in registers for the whole sequence
+  float4 bw[NQ][SW_MAXB];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    const float4* wp = reinterpret_cast<const float4*>(d.Wp) + (long)(q0 + n) * a.KB * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < SW_MAXB; ++i) {
+      const int jb = wave + 4 * i;
+      bw[n][i] = jb < a.KB ? wp[(long)jb * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // float offset (inside a slot) of this lane's 16-byte piece of K block jb: slice 4jb+lq, row li
+  int goff[SW_MAXB];
+#pragma unroll
+  for (int i = 0; i < SW_MAXB; ++i) {
+    const int jb = wave + 4 * i;
+    goff[i] = jb < a.KB ? ((4 * jb + lq) * 16 + li) * 4 : -1;
+  }
+  // gate-math ownership: wave n < NQ owns slice q0+n; lane -> (row bi, unit u); recurrent state lives in registers
+  const int bi = lane >> 2, u = lane & 3;
+  const bool gate_wave = wave < NQ;
+  const int qn = q0 + (gate_wave ? wave : 0);
+  const int b = b0 + bi, j = 4 * qn + u;
+  const bool live = gate_wave && b < B && j < H;
+  float hp = 0.f, cp = 0.f, yp = 0.f, br[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    hp = d.h0 ? d.h0[(long)b * d.h0_ld + j] : 0.f;
+    if (CELL == CELL_LSTM) cp = d.c0 ? d.c0[(long)b * d.c0_ld + j] : 0.f;
+    if (CELL == CELL_GRU && d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
+  }
+  const long pub_off = ((long)qn * 16 + bi) * 4;                          // this (slice, row)'s 16 bytes inside a slot
+  if (tid == 0) abort_flag = 0;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = d.reverse ? T - 1 - s : s;
+    // operands of the gate math that do not depend on the exchange
+    bool m = true;
+    float pre[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) pre[g] = 0.f;
+    if (live) {
+      m = a.mask ? a.mask[(long)b * T + t] != 0 : true;
+      const float* pr = d.pre + ((long)b * T + t) * NG * H + j;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) pre[g] = pr[(long)g * H];
+    }
+
+    // A operand: 16 rows x H of h_{s-1}
+    f32x4 av[SW_MAXB];
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < SW_MAXB; ++i) {
+        const int jb = wave + 4 * i;
+        av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (jb < a.KB && d.h0 != nullptr && b0 + li < B) {
+          const float* hr = d.h0 + (long)(b0 + li) * d.h0_ld + 16 * jb + 4 * lq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[i][e] = hr[e];
+        }
+      }
+    } else {
+      const float* src = xb + (long)((s - 1) & (SW_SLOTS - 1)) * slot_floats;
+      const float* p0 = src + (goff[0] >= 0 ? goff[0] : 0);
+      const float* p1 = src + (goff[1] >= 0 ? goff[1] : 0);
+      const float* p2 = src + (goff[2] >= 0 ? goff[2] : 0);
+      const float* p3 = src + (goff[3] >= 0 ? goff[3] : 0);
+      int spins = 0;
+      for (;;) {
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc1\n\t"
+            "global_load_dwordx4 %1, %5, off sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc1\n\t"
+            "global_load_dwordx4 %3, %7, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3])
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+            : "memory");
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < SW_MAXB; ++i)
+          if (goff[i] >= 0)
+            ok = ok && __float_as_uint(av[i].x) != SW_SENT && __float_as_uint(av[i].y) != SW_SENT && __float_as_uint(av[i].z) != SW_SENT &&
+                 __float_as_uint(av[i].w) != SW_SENT;
+        if (__all(ok)) break;
+        if (++spins > a.spin_limit || *(volatile int*)&abort_flag) { abort_flag = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int i = 0; i < SW_MAXB; ++i)
+        if (goff[i] < 0) av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SW_MAXB; ++i) {
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bw[n][i].x, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bw[n][i].y, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bw[n][i].z, acc[n], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bw[n][i].w, acc[n], 0, 0, 0);
+    }
+    float(*pt)[NQ][16 * 17] = part[s & 1];              // double-buffered: a wave may run one step ahead of the gate waves
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[wave][n][(lq * 4 + r) * 17 + li] = acc[n][r];
+    __syncthreads();
+    if (abort_flag) break;
+
+    if (gate_wave) {
+      float hnew = hp;
+      float sgv[4] = {0.f, 0.f, 0.f, 0.f};
+      float cn = cp;
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          sgv[g] = pt[0][wave][bi * 17 + g * 4 + u] + pt[1][wave][bi * 17 + g * 4 + u] + pt[2][wave][bi * 17 + g * 4 + u] +
+                   pt[3][wave][bi * 17 + g * 4 + u];
+        float hn;
+        if constexpr (CELL == CELL_LSTM) {
+          const float ig = sigmoidf_(pre[0] + sgv[0]), fg = sigmoidf_(pre[1] + sgv[1]);
+          const float gg = tanhf_(pre[2] + sgv[2]), og = sigmoidf_(pre[3] + sgv[3]);
+          const float c2 = fg * cp + ig * gg;
+          hn = og * tanhf_(c2);
+          cn = m ? c2 : cp;
+          sgv[0] = ig; sgv[1] = fg; sgv[2] = gg; sgv[3] = og;
+        } else if constexpr (CELL == CELL_GRU) {
+          const float z = sigmoidf_(pre[0] + sgv[0] + br[0]);
+          const float r = sigmoidf_(pre[1] + sgv[1] + br[1]);
+          const float arh = sgv[3] + br[2];
+          const float hh = tanhf_(pre[2] + sgv[2] + r * arh);
+          hn = z * hp + (1.f - z) * hh;
+          sgv[0] = z; sgv[1] = r; sgv[2] = hh; sgv[3] = arh;
+        } else {
+          hn = tanhf_(pre[0] + sgv[0]);
+          sgv[0] = hn;
+        }
+        hnew = m ? hn : hp;
+        yp = m ? hn : yp;
+      }
+      // publish first (it is on every other workgroup's critical path): lanes u == 0 gather their row's 4 units and store
+      // them as ONE 16-byte write-through store; then re-arm slot (s + 2) % 4 the same way
+      f32x4 pub;
+      pub.x = hnew;
+      pub.y = __shfl_down(hnew, 1, 64);
+      pub.z = __shfl_down(hnew, 2, 64);
+      pub.w = __shfl_down(hnew, 3, 64);
+      if (u == 0) {
+        float* dst = xb + (long)(s & (SW_SLOTS - 1)) * slot_floats + pub_off;
+        float* rearm = xb + (long)((s + 2) & (SW_SLOTS - 1)) * slot_floats + pub_off;
+        const float sf = __uint_as_float(SW_SENT);
+        const f32x4 sent = {sf, sf, sf, sf};
+        asm volatile(
+            "s_waitcnt vmcnt(0)\n\t"                      // (no-op after a gather; orders the first steps' stores)
+            "global_store_dwordx4 %0, %1, off sc1\n\t"
+            "global_store_dwordx4 %2, %3, off sc1" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
+      }
+      if (live) {
+        const long o = ((long)b * T + t) * H + j;
+        d.hseq[o] = hnew;
+        a.y[((long)b * T + t) * a.y_ld + d.y_col + j] = yp;
+        if (CELL == CELL_LSTM) d.cseq[o] = cn;
+        if (d.saved) {
+          float* sv2 = d.saved + ((long)b * T + t) * NS * H + j;
+#pragma unroll
+          for (int g = 0; g < NS; ++g) sv2[(long)g * H] = sgv[g];
+        }
+        cp = cn;
+        hp = hnew;
+      }
+    }
+  }
+  if (abort_flag && tid == 0) {
+    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static int sw_nq(int B, int H, int ndir) {
+  // slices per workgroup: 1 (one workgroup per 4 units, shortest matrix phase) unless that grid would not fit the chip
+  static const int forced = getenv("ASR_SWEEP_NQ") ? atoi(getenv("ASR_SWEEP_NQ")) : 0;
+  if ((forced == 1 || forced == 2) && (H / 4) % forced == 0) return forced;
+  const long wgs = (long)(H / 4) * asr_cdiv(B, 16) * ndir;
+  return wgs <= 256 ? 1 : 2;
+}
+
+// scratch the caller provides: exchange buffer + 32 words holding the per-launch error word (floats)
+extern "C" long asr_rnn_sweep_ws_floats(int B, int H, int ndir) {
+  const long groups = (long)ndir * asr_cdiv(B, 16), Q = asr_cdiv(H, 4);
+  return groups * SW_SLOTS * Q * 64 + 32;
+}
+
+// 1 when the one-launch sweep can run this layer (otherwise use asr_rnn_seq_fwd)
+extern "C" int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int ndir) {
+  if (rnn_type < 0 || rnn_type > 2 || B <= 0 || T < 2 || H <= 0 || H % 16 != 0 || H > 64 * SW_MAXB) return 0;
+  if (ndir != 1 && ndir != 2) return 0;
+  const long wgs = (long)(H / 4) * asr_cdiv(B, 16) * ndir;
+  return wgs <= 512 ? 1 : 0;                                             // two slices per workgroup above 256
+}
+
+template <int NQ>
+static void sw_launch(int rnn_type, dim3 grid, hipStream_t st, const SwArgs& a) {
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_LSTM, NQ>), grid, dim3(256), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_GRU, NQ>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_RNN, NQ>), grid, dim3(256), 0, st, a);
+}
+
+// Same contract as asr_rnn_seq_fwd (rnn.hip), one launch.  ws: asr_rnn_sweep_ws_floats() floats; the uint32 at
+// ws[ws_floats - 32] is non-zero after the call if a hand-off timed out (results invalid); err_flag (optional, device):
+// set to 1.0f in that case and never cleared by the library.
+extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, void* stream) {
+  ASR_CHECK(s && ws, ASR_ERR_ARG, "asr_rnn_sweep_fwd: null argument");
+  ASR_CHECK(asr_rnn_sweep_supported(s->rnn_type, s->B, s->T, s->H, s->ndir), ASR_ERR_UNSUPPORTED,
+            "asr_rnn_sweep_fwd: shape not supported (need H %% 16 == 0, H <= %d, <= 512 unit slices x batch tiles)", 64 * SW_MAXB);
+  const int B = s->B, T = s->T, H = s->H;
+  const bool lstm = s->rnn_type == CELL_LSTM;
+  hipStream_t st = (hipStream_t)stream;
+  const long groups = (long)s->ndir * asr_cdiv(B, 16), Q = H / 4;
+  const long xfloats = groups * SW_SLOTS * Q * 64;
+  SwArgs a{};
+  a.B = B; a.T = T; a.H = H; a.KB = H / 16;
+  a.mask = s->mask; a.y = s->y; a.y_ld = s->y_ld;
+  a.xbuf = ws;
+  a.err = reinterpret_cast<unsigned*>(ws + xfloats);
+  a.err_flag = err_flag;
+  a.spin_limit = g_spin_limit;
+  for (int d = 0; d < s->ndir; ++d) {
+    ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_sweep_fwd: null buffer (dir %d)", d);
+    ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_fwd: recurrent dropout is not supported (use asr_rnn_seq_fwd)");
+    SwDir& p = a.d[d];
+    p.pre = s->pre[d]; p.Wp = s->Wp[d]; p.bias_rec = s->bias_rec[d];
+    p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
+    p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d];
+    p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
+  }
+  // every exchange word is re-armed with the sentinel and the error word cleared on every call, by an ordinary kernel
+  // (graph-capturable; see asr_zero_async for why not a memset node)
+  {
+    const size_t n = (size_t)xfloats;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SW_SENT, a.err, 32);
+    ASR_LAUNCH_CHECK();
+  }
+  const int nq = sw_nq(B, H, s->ndir);
+  dim3 grid((unsigned)(Q / nq), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
+  if (nq == 1) sw_launch<1>(s->rnn_type, grid, st, a);
+  else sw_launch<2>(s->rnn_type, grid, st, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

@@ -139,10 +139,15 @@ class BiRNN:
     """BiRNN of las.py:62-126 on the step kernels: forward + backward LSTM/GRU/SimpleRNN over
     x [B,T,Din] with a frame mask, chained initial states and Keras input dropout."""
 
-    def __init__(self, store, prefix, rnn_type, Din, H, dropout, stream_in, device="cuda"):
+    def __init__(self, store, prefix, rnn_type, Din, H, dropout, stream_in, device="cuda", recurrent_dropout=0.0, stream_rec=None):
         ops.rnn_type_id(rnn_type)
         self.store, self.prefix, self.rt, self.Din, self.H = store, prefix, rnn_type, Din, H
         self.dropout, self.stream_in = float(dropout), stream_in
+        # las.py:84-105 / deepspeech2.py:95-107: Keras recurrent dropout = one [B,H] multiplier per call on h_tm1, constant
+        # over time (per direction).  Runs on the per-step kernels (the persistent launches do not take it).
+        self.recurrent_dropout, self.stream_rec = float(recurrent_dropout), stream_rec
+        if self.recurrent_dropout > 0 and stream_rec is None:
+            raise ValueError("recurrent_dropout needs an RNG stream id")
         self.cells = [ops.PackedCell(rnn_type, H, [H], device) for _ in range(2)]
         self.names = [prefix + d + "/cell/" for d in ("forward_rnn", "backward_rnn")]
 
@@ -167,6 +172,8 @@ class BiRNN:
         for d in range(2):
             dd = dict(pre=f(B, T, NG[rt] * H), hseq=f(B, T, H), mtab=f(B, self.Din), direct=f(B, H),
                       dy_carry=f(B, H), dh0=f(B, H), reverse=(d == 1), cell=self.cells[d])
+            if self.recurrent_dropout > 0:
+                dd["rtab"] = f(B, H)
             dd["saved"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
             if rt == "lstm":
                 dd["cseq"] = f(B, T, H)
@@ -188,8 +195,13 @@ class BiRNN:
         nst = 2 if rt == "lstm" else 1
         x2d = x3d.reshape(B * T, self.Din)
         drop = training and self.dropout > 0
+        rdrop = training and self.recurrent_dropout > 0
         for d, dd in enumerate(buf["dirs"]):
             p = self.store.p
+            dd["rec_mult"] = None
+            if rdrop:
+                ops.dropout_table(dd["rtab"], seed, self.stream_rec + d, self.recurrent_dropout)
+                dd["rec_mult"] = dd["rtab"]
             W, b = p[self.names[d] + "kernel"], p[self.names[d] + "bias"]
             if drop:
                 ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
@@ -205,9 +217,10 @@ class BiRNN:
         buf["mask"] = mask
         buf["x3d"] = x3d
         buf["drop"] = drop
+        buf["rdrop"] = rdrop
         buf["seq"] = ops.make_rnn_seq(rt, B, T, H, buf["dirs"], mask, buf["y"], [0, H])
         # one persistent launch for all T steps when the layer fits on the chip, else one launch per step
-        if PERSISTENT_RNN and ops.rnn_persist_supported(rt, B, T, H, 2):
+        if PERSISTENT_RNN and not rdrop and ops.rnn_persist_supported(rt, B, T, H, 2):
             if "persist_ws" not in buf:
                 buf["persist_ws"] = ops.rnn_persist_ws(B, H, 2, x3d.device)
             ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"])
@@ -230,7 +243,7 @@ class BiRNN:
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
                             dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"]))
         pws = None
-        if PERSISTENT_RNN and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
+        if PERSISTENT_RNN and not buf["rdrop"] and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
             if "persist_bwd_ws" not in buf:
                 buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
             pws = buf["persist_bwd_ws"]
@@ -247,16 +260,20 @@ class BiRNN:
                 cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
                 # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
                 hs = dd["hseq"]
+                # recurrent dropout: the cell multiplied (h_prev * rtab[b]) into U - scale the stored states the same way
+                # (one table row per batch entry: rows-per-group T covers a whole [T-1, H] slab, the slab index picks the row)
+                rs = dict(a_scale=dd["rtab"], a_rpg=T, a_scale_stride=H) if buf["rdrop"] else {}
+                rs0 = dict(a_scale=dd["rtab"], a_rpg=1) if buf["rdrop"] else {}
                 for s0, d0, n in slot_cols(rt, H, "rec"):
                     gU = g[nm + "recurrent_kernel"][:, d0:d0 + n]
                     if T > 1:
                         if dd["reverse"]:
-                            ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                            ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs)
                         else:
-                            ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                            ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs)
                     if dd["h0"] is not None:
                         t0 = T - 1 if dd["reverse"] else 0
-                        ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
+                        ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs0)
 
         if side is not None:
             side.run(param_grads)

@@ -106,7 +106,8 @@ class DeepSpeech2(ModelProto):
         din = self.D0
         for i in range(self.Lr):
             self.layers.append(BiRNN(self.store, f"recurrent/rnn_layers/{i}/", self.rt, din, self.H, self.dropout,
-                                     R.STREAM_ENC_IN + 2 * i, self.device))
+                                     R.STREAM_ENC_IN + 2 * i, self.device, recurrent_dropout=self.recurrent_dropout,
+                                     stream_rec=R.STREAM_ENC_REC + 2 * i))
             din = 2 * self.H
         self.built = True
         self.weights_changed()
@@ -171,8 +172,6 @@ class DeepSpeech2(ModelProto):
     # ------------------------------------------------------------------------------------------ forward
     def forward_ws(self, ws, audio, training, use_teacher_forcing=True):
         """DeepSpeech2.call (deepspeech2.py:174-178)."""
-        if training and self.recurrent_dropout > 0:
-            raise NotImplementedError("recurrent_dropout > 0 is not supported (0.0 in every shipped config)")
         if self._packed_version != self._version:
             self.pack_weights()
         p, B, T2, H = self.store.p, ws.B, ws.T2, self.H

@@ -288,7 +288,7 @@ def f32_to_bf16(src: torch.Tensor, dst: torch.Tensor):
 
 
 def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias=None, relu=False, a_scale=None,
-         a_rpg=0, c_scale=None, c_rpg=0, split_k=1, compute=None):
+         a_rpg=0, c_scale=None, c_rpg=0, split_k=1, compute=None, a_scale_stride=0):
     """c (+)= alpha * op(a) @ op(b) (+ bias).  2-D operands, or 3-D with a leading batch axis; a 2-D `c`
     with 3-D a/b means split-K over the batch axis (atomic accumulation, requires accumulate).
     compute: None = the process-wide mode (set_mixed_precision), 0 = f32 operands, 1 = bf16 operands."""
@@ -308,7 +308,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     d.stride_a = a.stride(0) if a.dim() == 3 else 0
     d.stride_b = b.stride(0) if b.dim() == 3 else 0
     d.stride_c = c.stride(0) if c.dim() == 3 else 0
-    d.stride_a_scale = 0
+    d.stride_a_scale = int(a_scale_stride)     # per-batch offset (elements) into a_scale for 3-D operands
     d.alpha = alpha
     d.accumulate = int(accumulate)
     if batch > 1 and c.dim() == 2:
@@ -388,7 +388,7 @@ def make_rnn_seq(rnn_type, B, T, H, dirs, mask, y, y_cols):
     s.h0_ld = _arr2([d["h0"].stride(0) if d.get("h0") is not None else 0 for d in dirs], C.c_long)
     s.c0 = _arr2([d.get("c0") for d in dirs])
     s.c0_ld = _arr2([d["c0"].stride(0) if d.get("c0") is not None else 0 for d in dirs], C.c_long)
-    s.rec_mult = _arr2([None for _ in dirs])
+    s.rec_mult = _arr2([d.get("rec_mult") for d in dirs])
     s.mask = mask.data_ptr() if mask is not None else None
     s.hseq = _arr2([d["hseq"] for d in dirs])
     s.cseq = _arr2([d.get("cseq") for d in dirs])

@@ -1,0 +1,391 @@
+"""GPU parity on the SHIPPED configurations at their real geometry (BASELINE.json configs), and whole-model
+parity through the kernels the benchmark actually times:
+
+  * las_small.yml + libri_config.yml: raw 10 s audio -> fused front end with SpecAugment -> LAS forward (training,
+    dropout, teacher forcing) -> masked cross-entropy -> every parameter gradient, against the float64 oracle; the
+    encoder runs the persistent one-launch recurrent kernels (asserted);
+  * deepspeech.yml + libri_config.yml: raw 15 s audio -> front end -> DeepSpeech2 -> CTC -> every gradient;
+  * las_large.yml (H = 1024: the wide / staged step kernels) in f32 and under --mixed-precision (bf16 operands);
+  * a small LAS / DeepSpeech2 whose hidden sizes are multiples of 16 and whose batch spans two 16-row tiles, with
+    ragged and interior masks, so that every BiRNN layer of the whole-model gradient check takes the persistent
+    forward AND backward launches (asserted) - reference models/las.py:349-380, models/deepspeech2.py:174-178.
+
+Tolerances (f32 kernels against a float64 oracle; the loss bound is north_star's): loss 1e-3 absolute, logits 1e-3 of
+their range, gradients 5e-3 of each tensor's largest entry at full size (f32 sums over ~10^5 terms), 2e-3 on the small
+models; mixed precision: bf16 operand rounding, 5e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import deepspeech2 as ODS
+from oracle import features as OF
+from oracle import las as OLAS
+from oracle import measure as OM
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = os.path.join(ROOT, "resources", "configs")
+SAMPLE_RATE = 16000
+
+
+def _yaml(name):
+    with open(os.path.join(CONFIGS, name)) as f:
+        return yaml.safe_load(f)
+
+
+def _frontend(spec_augment=True):
+    from speech_recognition_amd import ops
+    dc = _yaml("libri_config.yml")
+    sa = dict(dc["spec_augment"], enable=spec_augment)
+    plan = ops.LogmelPlan(dc["sample_rate"], dc["frame_length"], dc["frame_step"], dc["fft_length"], dc["num_mel_bins"],
+                          dc["lower_edge_hertz"], dc["upper_edge_hertz"], use_delta=dc["use_delta_accelerate"], spec_augment=sa)
+    return dc, plan
+
+
+def _audio(B, seconds, short=None, seed=1234):
+    """SURVEY 8d synthetic clips: N(0, 0.1^2) clipped to [-1, 1]; `short` = {row: seconds} gives ragged lengths."""
+    g = np.random.default_rng(seed)
+    N = int(seconds * SAMPLE_RATE)
+    audio = np.clip(g.standard_normal((B, N), dtype=np.float32) * 0.1, -1.0, 1.0)
+    n = np.full((B,), N, np.int32)
+    for row, s in (short or {}).items():
+        n[row] = int(s * SAMPLE_RATE)
+        audio[row, n[row]:] = 0.0
+    return audio, n
+
+
+def _tokens(B, L, V, ragged=None, seed=4321, lo=17):
+    g = np.random.default_rng(seed)
+    toks = g.integers(lo, V, size=(B, L), dtype=np.int32)
+    toks[:, 0], toks[:, -1] = 2, 3
+    for row, n in (ragged or {}).items():
+        toks[row, n - 1] = 3
+        toks[row, n:] = 0
+    return toks
+
+
+def _features(plan, dc, audio, n, seed, spec_augment=True):
+    """HIP front end and its float64 oracle on the same clips / same SpecAugment draws."""
+    feats = plan(torch.from_numpy(audio).cuda(), torch.from_numpy(n).cuda(), plan.num_frames(audio.shape[1]),
+                 seed=torch.tensor([seed], dtype=torch.int32, device="cuda") if spec_augment else None)
+    sa = {k: dc["spec_augment"][k] for k in ("F", "m_F", "T", "p", "m_T")} if spec_augment else None
+    ref = OF.batch_features(audio.astype(np.float64), n, dc, seed=seed, spec_aug=sa)
+    assert tuple(feats.shape) == ref.shape
+    err = float(np.abs(feats.cpu().numpy() - ref).max())
+    assert err < 2e-3, f"front end: max abs error {err:.2e} (log-mel values span ~[-28, 5])"
+    # padded frames are exact zeros (padded_batch semantics, run/train.py:189-197), as are the SpecAugment masks
+    assert bool(((feats.cpu().numpy() == 0.0) == (ref == 0.0)).all())
+    return feats, torch.from_numpy(ref)
+
+
+def _leaves(model):
+    vals = {k: v.double() for k, v in model.state_dict().items()}
+    return {k: v.clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k, v in vals.items()}
+
+
+def _check_grads(model, leaves, tol, min_named=()):
+    """Every parameter gradient against autograd on the oracle, normalised by the tensor's largest reference entry; all
+    offenders are listed (not only the first)."""
+    worst, worst_name, bad = 0.0, None, []
+    grads = model.store.grads()
+    for n in min_named:
+        assert n in grads, n
+    for n, gten in grads.items():
+        ref = leaves[n].grad
+        assert ref is not None, n
+        assert bool(torch.isfinite(gten).all()), n
+        scale = max(float(ref.abs().max()), 1e-4)
+        err = float((gten.double().cpu() - ref).abs().max()) / scale
+        if err > worst:
+            worst, worst_name = err, n
+        if not err < tol:
+            bad.append(f"{n}: {err:.2e} (max |ref| {float(ref.abs().max()):.2e})")
+    assert not bad, f"gradients beyond the normalised tolerance {tol:.0e}: " + "; ".join(bad)
+    return worst, worst_name
+
+
+def _persistent_layers(ws):
+    """The BiRNN buffers of a workspace and whether their last forward / backward took the persistent launches."""
+    from speech_recognition_amd import ops
+    out = []
+    for lw in ws.layers:
+        buf = lw["rnn"]
+        for key in ("persist_ws", "persist_bwd_ws"):
+            if key in buf:
+                assert not ops.rnn_persist_error(buf[key]), f"{key}: a hand-off timed out"
+        out.append(("persist_ws" in buf, "persist_bwd_ws" in buf))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- las_small.yml, real geometry
+LAS_NAMED = ("attend_and_speller/feedforward/kernel", "attend_and_speller/embedding/embeddings",
+             "attend_and_speller/decoder_layers/0/cell/recurrent_kernel", "attend_and_speller/attention/key_weight/kernel",
+             "listener/encoder_layers/0/forward_rnn/cell/recurrent_kernel", "listener/encoder_layers/2/backward_rnn/cell/kernel",
+             "listener/projection/1/kernel", "listener/batch_norm/0/gamma", "listener/conv1/kernel", "listener/hidden_states_proj/kernel")
+
+
+@pytest.mark.parametrize("B", [4])
+def test_las_small_yml_training_step_at_full_geometry(B):
+    """BASELINE configs[1] geometry (10 s clips, 65-token rows, SpecAugment on, dropout 0.15) at batch 4, one clip shorter
+    and one token row padded: features, logits, loss (1e-3), accuracy counts and EVERY gradient against the oracle."""
+    from speech_recognition_amd import layers, ops
+    from speech_recognition_amd.configs import get_model_config
+    assert layers.PERSISTENT_RNN
+    mc = _yaml("las_small.yml")
+    dc, plan = _frontend()
+    seed = 20211
+    audio, n = _audio(B, 10.0, short={1: 7.3})
+    toks = _tokens(B, 65, mc["vocab_size"], ragged={2: 41})
+    feats, ref_feats = _features(plan, dc, audio, n, seed)
+    assert tuple(feats.shape) == (B, 999, 80, 3)
+
+    model = get_model_config(os.path.join(CONFIGS, "las_small.yml")).create_model(seed=7)
+    model.build(80, 3)
+    model.state[1] = seed
+    leaves = _leaves(model)
+    t = torch.from_numpy(toks)
+    logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+    loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
+    loss_r.backward()
+    correct_r, count_r = OM.sparse_categorical_accuracy(t[:, 1:], logits_r.detach(), 0)
+
+    ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+    assert (ws.T2, ws.U) == (249, 64)
+    model.set_targets(ws, t.cuda(), labels)
+    ops.fill(model.store.grad, 0.0)
+    model.forward_ws(ws, feats, True, True)
+    out = ws.logits.view(ws.U, B, -1).permute(1, 0, 2)
+    assert_close(out, logits_r, 1e-3, "las_small training logits")
+    model.loss_and_grad(ws, labels)
+    model.backward_ws(ws, feats)
+    torch.cuda.synchronize()
+    st = ws.stats.cpu().numpy()
+    assert abs(st[0] - float(loss_r.detach())) < 1e-3, (st[0], float(loss_r))
+    assert st[2] == count_r and abs(st[1] - correct_r) <= 1          # an arg-max tie may flip one of the 243 positions
+    assert all(f and b for f, b in _persistent_layers(ws)), "the encoder layers must run the persistent kernels the benchmark times"
+    worst = _check_grads(model, leaves, 5e-3, LAS_NAMED)
+    print(f"las_small B={B}: loss {st[0]:.5f} (oracle {float(loss_r):.5f}), worst gradient {worst}")
+
+
+def test_las_small_yml_reference_fixture_batch():
+    """BASELINE configs[0]: las_small + libri_config on the reference's own tests/data/wav_dataset.tsv (two silent clips,
+    batch 2, SpecAugment off as shipped), forward + loss + gradients against the oracle."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.configs import get_model_config
+    from speech_recognition_amd.data import SentencePieceTokenizer, get_dataset
+    fix = os.path.join(ROOT, "tests", "golden", "reference_fixtures")
+    tok = SentencePieceTokenizer(os.path.join(fix, "sp_model_unigram_16K_libri.model"))
+    ex = list(get_dataset(os.path.join(fix, "wav_dataset.tsv"), "wav", 16000, tok))
+    L = max(len(t) for _, t in ex)
+    audio = np.stack([a for a, _ in ex]).astype(np.float32)
+    toks = np.stack([np.pad(t, (0, L - len(t))) for _, t in ex]).astype(np.int32)
+    n = np.full((len(ex),), audio.shape[1], np.int32)
+    mc = _yaml("las_small.yml")
+    dc, plan = _frontend(spec_augment=False)
+    feats, ref_feats = _features(plan, dc, audio, n, 0, spec_augment=False)
+    assert feats.shape[1] == 412                                       # reference tests/test_data.py:53-57
+    model = get_model_config(os.path.join(CONFIGS, "las_small.yml")).create_model(seed=11)
+    model.build(80, 3)
+    seed = 5
+    model.state[1] = seed
+    leaves = _leaves(model)
+    t = torch.from_numpy(toks)
+    logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+    loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
+    loss_r.backward()
+    ws, labels = model.train_workspace(len(ex), feats.shape[1], L)
+    model.set_targets(ws, t.cuda(), labels)
+    ops.fill(model.store.grad, 0.0)
+    model.forward_ws(ws, feats, True, True)
+    model.loss_and_grad(ws, labels)
+    model.backward_ws(ws, feats)
+    torch.cuda.synchronize()
+    assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
+    _check_grads(model, leaves, 5e-3, LAS_NAMED)
+
+
+# ---------------------------------------------------------------------------------------------- deepspeech.yml, real geometry
+def test_deepspeech_yml_training_step_at_full_geometry():
+    """BASELINE configs[3] geometry (15 s clips, 96 CTC labels, blank 14, mask mode 'intended') at batch 2, one clip shorter."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.configs import get_model_config
+    mc = _yaml("deepspeech.yml")
+    dc, plan = _frontend()
+    seed = 777
+    B = 2
+    audio, n = _audio(B, 15.0, short={1: 11.0}, seed=99)
+    toks = _tokens(B, 96, mc["vocab_size"], ragged={1: 70})
+    feats, ref_feats = _features(plan, dc, audio, n, seed)
+    assert tuple(feats.shape) == (B, 1499, 80, 3)
+    model = get_model_config(os.path.join(CONFIGS, "deepspeech.yml")).create_model(seed=3)
+    model.build(80, 3)
+    model.state[1] = seed
+    leaves = _leaves(model)
+    cfg = dict(mc)
+    logits_r, aux = ODS.ds2_forward(leaves, cfg, ref_feats, training=True, seed=seed, return_aux=True)
+    loss_r, per_r = OM.ctc_loss(torch.from_numpy(toks), logits_r, mc["blank_index"], mc.get("pad_index", 0))
+    loss_r.backward()
+    ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+    assert ws.T2 == 168
+    model.set_targets(ws, torch.from_numpy(toks).cuda(), labels)
+    ops.fill(model.store.grad, 0.0)
+    model.forward_ws(ws, feats, True)
+    assert torch.equal(ws.mask.bool().cpu(), aux["mask"])
+    assert_close(ws.logits.view(B, ws.T2, -1), logits_r, 1e-3, "deepspeech training logits")
+    model.loss_and_grad(ws, labels)
+    model.backward_ws(ws, feats)
+    torch.cuda.synchronize()
+    assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3, (float(ws.stats[0]), float(loss_r))
+    assert_close(ws.per_sample, per_r, 1e-4, "per-sample CTC loss")
+    assert all(f and b for f, b in _persistent_layers(ws)), "the GRU layers must run the persistent kernels the benchmark times"
+    _check_grads(model, leaves, 5e-3, ("fully_connected/kernel", "convolution/conv_layers/0/kernel", "convolution/conv_layers/2/kernel",
+                                       "recurrent/rnn_layers/0/forward_rnn/cell/kernel", "recurrent/rnn_layers/6/backward_rnn/cell/recurrent_kernel",
+                                       "recurrent/batch_norm/3/gamma"))
+
+
+# ---------------------------------------------------------------------------------------------- las_large.yml (H = 1024)
+@pytest.mark.parametrize("mixed", [False, True])
+def test_las_large_yml_training_step_wide_kernels(mixed):
+    """las_large.yml (He = Hd = 1024: the wide forward and the LDS-staged backward step kernels, which need more than one batch
+    tile) at batch 18, 2 s clips, 9-token rows; f32 against the oracle, and --mixed-precision (bf16 operands, BASELINE
+    configs[4]) within bf16 rounding of it."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.configs import get_model_config
+    mc = _yaml("las_large.yml")
+    dc, plan = _frontend()
+    seed = 31
+    B = 18
+    audio, n = _audio(B, 2.0, short={3: 1.4, 17: 0.9}, seed=5)
+    toks = _tokens(B, 9, mc["vocab_size"], ragged={5: 6})
+    feats, ref_feats = _features(plan, dc, audio, n, seed)
+    ops.set_mixed_precision(mixed)
+    try:
+        model = get_model_config(os.path.join(CONFIGS, "las_large.yml")).create_model(seed=13)
+        model.build(80, 3)
+        model.state[1] = seed
+        leaves = _leaves(model)
+        t = torch.from_numpy(toks)
+        logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+        loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
+        loss_r.backward()
+        ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+        model.set_targets(ws, t.cuda(), labels)
+        ops.fill(model.store.grad, 0.0)
+        model.pack_weights()
+        model.forward_ws(ws, feats, True, True)
+        out = ws.logits.view(ws.U, B, -1).permute(1, 0, 2)
+        assert_close(out, logits_r, 5e-2 if mixed else 1e-3, "las_large training logits")
+        model.loss_and_grad(ws, labels)
+        model.backward_ws(ws, feats)
+        torch.cuda.synchronize()
+        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < (3e-2 if mixed else 1e-3), (float(ws.stats[0]), float(loss_r))
+        assert not any(f or b for f, b in _persistent_layers(ws)), "H = 1024 is beyond the persistent kernels: the step kernels run"
+        _check_grads(model, leaves, 8e-2 if mixed else 5e-3, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
+                                                               "attend_and_speller/decoder_layers/1/cell/kernel"))
+    finally:
+        ops.set_mixed_precision(False)
+
+
+# ---------------------------------------------------------------------------------------------- whole models through the persistent kernels
+def _las_small_model(rt, V=61, He=32, Hd=32):
+    from speech_recognition_amd.models import LAS
+    cfg = dict(rnn_type=rt, vocab_size=V, encoder_hidden_dim=He, decoder_hidden_dim=Hd, num_encoder_layers=2, num_decoder_layers=2,
+               dropout=0.15, teacher_forcing_rate=0.99, pad_id=0)
+    m = LAS(rt, V, He, Hd, 2, 2, 0.15, 0.99, 0, seed=5)
+    m.build(20, 3)
+    g = torch.Generator().manual_seed(8)
+    vals = {}
+    for n, s in m.store.shapes.items():
+        vals[n] = torch.rand(s, generator=g) + 0.5 if n.endswith("gamma") else torch.randn(s, generator=g) * (0.5 if "embedding" in n else 0.2)
+    for n, v in m.buffers.items():
+        vals[n] = torch.rand(v.shape, generator=g) + 0.5 if n.endswith("variance") else torch.randn(v.shape, generator=g) * 0.1
+    m.load_state_dict(vals)
+    return m, cfg
+
+
+@pytest.mark.parametrize("rt", ["lstm", "gru"])
+def test_las_whole_model_gradients_through_persistent_kernels(rt):
+    """He = Hd = 32 and B = 19 (two 16-row batch tiles), ragged clip ends and interior all-zero frames: both encoder layers take
+    rnn_seq_fwd_persist / rnn_seq_bwd_persist (asserted); loss and EVERY gradient against torch.autograd on the oracle."""
+    from speech_recognition_amd import layers, ops
+    assert layers.PERSISTENT_RNN
+    m, cfg = _las_small_model(rt)
+    B, T, U = 19, 70, 6
+    g = torch.Generator().manual_seed(3)
+    audio = torch.randn(B, T, 20, 3, generator=g)
+    audio[1, 45:] = 0.0
+    audio[7, 20:] = 0.0
+    audio[18, 60:] = 0.0
+    audio[2, 8:14] = 0.0               # interior zero frames -> non-contiguous mask
+    audio[16, 30:38] = 0.0
+    audio[5] = 0.0                     # a fully masked row
+    tokens = torch.randint(1, cfg["vocab_size"], (B, U), generator=g, dtype=torch.int32)
+    labels = torch.randint(1, cfg["vocab_size"], (B, U), generator=g, dtype=torch.int32)
+    tokens[1, 3:] = 0
+    labels[1, 3:] = 0
+    seedv = 4242
+    m.state[1] = seedv
+    leaves = _leaves(m)
+    logits_r, aux = OLAS.las_forward(leaves, cfg, audio.double(), tokens, training=True, seed=seedv, use_teacher_forcing=True, return_aux=True)
+    loss_r = OM.sparse_categorical_crossentropy(labels, logits_r, 0)
+    loss_r.backward()
+    ws = m._workspace(B, T, U)
+    ws.toks_T[:U].copy_(tokens.t().cuda())
+    ag = audio.cuda()
+    m.forward_ws(ws, ag, True, True)
+    assert_close(ws.logits.view(U, B, -1).permute(1, 0, 2), logits_r, 3e-4, "training logits")
+    ops.fill(m.store.grad, 0.0)
+    m.loss_and_grad(ws, labels.t().contiguous().cuda())
+    m.backward_ws(ws, ag)
+    torch.cuda.synchronize()
+    assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
+    assert _persistent_layers(ws) == [(True, True)] * 2
+    _check_grads(m, leaves, 2e-3)
+    for n, v in m.buffers.items():
+        assert_close(v, aux["bn_updates"][n], 1e-4, n)
+
+
+@pytest.mark.parametrize("rt", ["gru", "rnn"])
+def test_ds2_whole_model_gradients_through_persistent_kernels(rt):
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.models import DeepSpeech2
+    cfg = dict(num_conv_layers=2, channels=[4, 6], kernel_sizes=[[11, 5], [5, 3]], strides=[[2, 2], [2, 1]], rnn_type=rt,
+               num_reccurent_layers=3, hidden_dim=16, dropout=0.1, recurrent_dropout=0.0, vocab_size=17, blank_index=3, pad_index=0)
+    m = DeepSpeech2(2, cfg["channels"], cfg["kernel_sizes"], cfg["strides"], rt, 3, 16, 0.1, 0.0, 17, 3, 0, seed=3)
+    m.build(20, 3)
+    g = torch.Generator().manual_seed(21)
+    vals = {}
+    for n, s in list(m.store.shapes.items()) + [(k, tuple(v.shape)) for k, v in m.buffers.items()]:
+        vals[n] = torch.rand(s, generator=g) + 0.5 if n.endswith(("gamma", "moving_variance")) else torch.randn(s, generator=g) * 0.3
+    m.load_state_dict(vals)
+    B, T, L = 18, 77, 5
+    audio = torch.randn(B, T, 20, 3, generator=g)
+    audio[1, 40:] = 0.0
+    audio[17, 61:] = 0.0
+    audio[9, 16:32] = 0.0
+    labels = torch.randint(4, 17, (B, L), generator=g, dtype=torch.int32)
+    labels[2, 3:] = 0
+    seedv = 99
+    m.state[1] = seedv
+    leaves = _leaves(m)
+    logits_r, aux = ODS.ds2_forward(leaves, cfg, audio.double(), training=True, seed=seedv, return_aux=True)
+    loss_r, per_r = OM.ctc_loss(labels, logits_r, 3, 0)
+    loss_r.backward()
+    ws, lab = m.train_workspace(B, T, L)
+    m.set_targets(ws, labels.cuda(), lab)
+    ag = audio.cuda()
+    m.forward_ws(ws, ag, True)
+    assert_close(ws.logits.view(B, ws.T2, -1), logits_r, 3e-4, "training logits")
+    ops.fill(m.store.grad, 0.0)
+    m.loss_and_grad(ws, lab)
+    m.backward_ws(ws, ag)
+    torch.cuda.synchronize()
+    assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
+    assert _persistent_layers(ws) == [(True, True)] * 3
+    _check_grads(m, leaves, 2e-3)
