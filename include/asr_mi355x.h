@@ -207,8 +207,11 @@ typedef struct asr_lr_schedule {
 int asr_lr_schedule_init(asr_lr_schedule* s, long total_steps, double max_learning_rate, double min_learning_rate,
                          double warmup_rate, long warmup_steps, long offset_steps);
 int asr_adam_step(float* params, const float* grads, float* m, float* v, long n, const int32_t* state,
-                  const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
-int asr_advance_state(int32_t* state, void* stream);
+                  const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, const float* skip_flag,
+                  void* stream);
+/* skip_flag (optional device float): when non-zero the step is invalid (a hand-off of a one-launch sweep timed out): Adam leaves
+ * parameters and moments untouched, asr_advance_state sets the sticky error word state[2] instead of counting the step. */
+int asr_advance_state(int32_t* state, const float* skip_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CTC (measure.py:24-42 CTCLoss on tf.nn.ctc_loss): labels [B, L] int32 zero(pad)-padded dense rows,
@@ -333,15 +336,6 @@ typedef struct asr_rnn_seq {
   float* saved[2];
 } asr_rnn_seq;
 int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream);
-/* The same layer forward as ONE persistent launch (workgroups stay resident over all T steps and hand
- * h_t to each other through global memory; every spin is bounded).  Supported when H % 16 == 0,
- * H <= 256, T >= 2 and ceil(H/4) * ceil(B/16) * ndir <= 256 workgroups.  ws: scratch of
- * asr_rnn_persist_ws_floats() floats; word [ws_floats - 32] (as uint32) is non-zero after the call if a
- * hand-off timed out (results invalid - rerun with asr_rnn_seq_fwd). */
-long asr_rnn_persist_ws_floats(int B, int H, int ndir);
-int asr_rnn_persist_supported(int rnn_type, int B, int T, int H, int ndir);
-int asr_rnn_seq_fwd_persist(const asr_rnn_seq* s, float* ws, void* stream);
-
 typedef struct asr_rnn_seq_grad {
   const float* dy; long dy_ld;              /* gradient wrt y, same layout as y                      */
   const float* dh_last[2]; long dh_last_ld[2]; /* gradient wrt the final h state or NULL            */
@@ -352,12 +346,25 @@ typedef struct asr_rnn_seq_grad {
 } asr_rnn_seq_grad;
 /* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs. */
 int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* stream);
-/* The same backward-through-time as ONE persistent launch (results equal to fp32 rounding; g->direct and
- * g->dy_carry are unused).  Supported when H % 16 == 0, G*H <= 1024, T >= 2 and
- * ceil(H/16) * ceil(B/16) * ndir <= 256 workgroups.  ws / error word as for asr_rnn_seq_fwd_persist. */
-long asr_rnn_persist_bwd_ws_floats(int B, int H, int ndir);
-int asr_rnn_persist_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
-int asr_rnn_seq_bwd_persist(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, void* stream);
+/* The same layer forward / backward-through-time as ONE launch each (rnn_sweep.hip / rnn_sweep_bwd.hip): workgroups stay
+ * resident over all T steps, keep their slice of the recurrent kernel in registers and hand the recurrent quantity to each
+ * other through global memory as self-validating 16-byte pieces (a sentinel NaN pattern marks "not written yet": no tags, no
+ * flags, no fences).  Forward: every workgroup owns 4 (or 8) hidden units x all gates and gathers h_{t-1} of its 16 batch rows;
+ * backward: a square of workgroups per (direction, batch tile) splits ds x U^T over both its axes, so a workgroup publishes one
+ * [16 x KU] block of partial dh and gathers 16 x H floats.  Same contracts as asr_rnn_seq_fwd / asr_rnn_seq_bwd (g->direct and
+ * g->dy_carry are unused; results equal to fp32 rounding, the forward bit for bit).  Supported when H % 16 == 0, H <= 256,
+ * T >= 2 and the grid fits the chip (asr_rnn_sweep[_bwd]_supported); every spin is bounded.  ws: asr_rnn_sweep[_bwd]_ws_floats() floats, re-armed by every call; the uint32 at
+ * ws[ws_floats - 32] is non-zero after the call if a hand-off timed out (results invalid); err_flag: optional device float
+ * that is set to 1.0f in that case and never cleared by the library (TrainStep's sticky error cell).
+ * asr_rnn_sweep_set_spin_limit: polls before a hand-off gives up (default 2^18, about 0.3 s; tests force time-outs with 0). */
+long asr_rnn_sweep_ws_floats(int B, int H, int ndir);
+int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int ndir);
+int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, void* stream);
+long asr_rnn_sweep_bwd_ws_floats(int B, int H, int ndir);
+int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
+int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, float* err_flag, void* stream);
+void asr_rnn_sweep_set_spin_limit(int polls);
+int asr_rnn_sweep_spin_limit(void);
 
 /* The same two steps with the two streamed operands given as bf16 images (asr_f32_to_bf16 of Kq and enc, made once per
  * training step): --mixed-precision.  The streams are what these kernels move, so the images halve their time; every

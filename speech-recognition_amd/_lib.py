@@ -129,12 +129,14 @@ SIGNATURES = {
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),
-    "asr_rnn_persist_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
-    "asr_rnn_persist_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "asr_rnn_seq_fwd_persist": (C.c_int, [C.POINTER(RnnSeq), _P, _P]),
-    "asr_rnn_persist_bwd_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
-    "asr_rnn_persist_bwd_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "asr_rnn_seq_bwd_persist": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P, _P]),
+    "asr_rnn_sweep_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_sweep_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_sweep_fwd": (C.c_int, [C.POINTER(RnnSeq), _P, _P, _P]),
+    "asr_rnn_sweep_bwd_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_sweep_bwd_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_sweep_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P, _P, _P]),
+    "asr_rnn_sweep_set_spin_limit": (None, [C.c_int]),
+    "asr_rnn_sweep_spin_limit": (C.c_int, []),
     "asr_conv2d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asr_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_uint32, C.c_float, _P]),
     "asr_conv2d_bwd_filter": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
@@ -161,8 +163,8 @@ SIGNATURES = {
     "asr_softmax_xent": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
     "asr_lr_schedule_init": (C.c_int, [C.POINTER(LrSchedule), c_long, C.c_double, C.c_double, C.c_double, c_long, c_long]),
     "asr_adam_step": (C.c_int, [_P, _P, _P, _P, c_long, _P, C.POINTER(LrSchedule), C.c_float, C.c_float, C.c_float,
-                                C.c_float, _P]),
-    "asr_advance_state": (C.c_int, [_P, _P]),
+                                C.c_float, _P, _P]),
+    "asr_advance_state": (C.c_int, [_P, _P, _P]),
     "asr_ctc_workspace_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
     "asr_ctc_loss": (C.c_int, [_P, c_long, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int,
                                C.c_float, _P]),

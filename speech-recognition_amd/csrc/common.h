@@ -109,9 +109,48 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each, absolute
 // error of the results ~1e-7).  The gate math of a recurrent step runs on ONE wave per workgroup and
 // sits on the step's critical path, so the ~100-instruction ocml expf/tanhf forms cost ~1 us per step.
-__device__ __forceinline__ float fast_exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + fast_exp_(-x)); }
+// Contraction is pinned off in these helpers: the step kernels and the one-launch sweeps inline them into different
+// surroundings and must produce the same bits (the tests compare them with torch.equal).
+__device__ __forceinline__ float fast_exp_(float x) {
+#pragma clang fp contract(off)
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+}
+__device__ __forceinline__ float sigmoidf_(float x) {
+#pragma clang fp contract(off)
+  return __builtin_amdgcn_rcpf(1.f + fast_exp_(-x));
+}
 __device__ __forceinline__ float tanhf_(float x) {
+#pragma clang fp contract(off)
   const float t = fast_exp_(-2.f * fabsf(x));
   return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+}
+
+// Forward gate math of one (batch row, hidden unit) pair - Keras LSTM / GRU(reset_after) / SimpleRNN cells (las.py:10-17 via
+// tf.keras.layers.*).  CELL: 0 LSTM, 1 GRU, 2 SimpleRNN.  pre[g]: input projection (+ bias) per gate,
+// s[slot]: recurrent sums in the packed slot order (LSTM i,f,c~,o; GRU z, r, x-part of h~ (unused), recurrent part of h~),
+// br: GRU recurrent bias, hpm: previous h times the recurrent-dropout multiplier (= hp without it), cp: previous c.
+// Out: hn (new h before the step mask), c2 (new c before the step mask), sv[4] the activations saved for backward.
+template <int CELL>
+__device__ __forceinline__ void asr_cell_forward(const float* pre, const float* s, const float* br, float hpm, float cp, float& hn, float& c2,
+                                                 float (&sv)[4]) {
+#pragma clang fp contract(off)
+  if constexpr (CELL == 0) {
+    const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
+    const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
+    c2 = fg * cp + ig * gg;
+    hn = og * tanhf_(c2);
+    sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og;
+  } else if constexpr (CELL == 1) {
+    const float z = sigmoidf_(pre[0] + s[0] + br[0]);
+    const float r = sigmoidf_(pre[1] + s[1] + br[1]);
+    const float arh = s[3] + br[2];
+    const float hh = tanhf_(pre[2] + s[2] + r * arh);
+    hn = z * hpm + (1.f - z) * hh;
+    c2 = 0.f;
+    sv[0] = z; sv[1] = r; sv[2] = hh; sv[3] = arh;
+  } else {
+    hn = tanhf_(pre[0] + s[0]);
+    c2 = 0.f;
+    sv[0] = hn; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f;
+  }
 }

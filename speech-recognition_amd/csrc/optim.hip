@@ -5,13 +5,15 @@
 // advances them on every replay.
 #include "common.h"
 
-// state (device, int32 x 4): [0] iterations (number of steps applied), [1] dropout seed, [2..3] reserved
+// state (device, int32 x 4): [0] iterations (number of steps applied), [1] dropout seed, [2] sticky error word (set by
+// advance_state when the step's skip flag was raised; cleared only by the host), [3] reserved
 struct AdamArgs {
   float* p; const float* g; float* m; float* v;
   long n;
   const int32_t* state;
   asr_lr_schedule lr;
   float beta1, beta2, eps, grad_scale;
+  const float* skip;       // optional: a non-zero value means the step's gradients are invalid - leave everything untouched
 };
 
 __device__ __forceinline__ float lr_at(const asr_lr_schedule& s, float step) {
@@ -22,6 +24,7 @@ __device__ __forceinline__ float lr_at(const asr_lr_schedule& s, float step) {
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  if (a.skip != nullptr && *a.skip != 0.f) return;
   const int it = a.state[0];
   const float t = (float)(it + 1);
   const float lr = lr_at(a.lr, (float)it);
@@ -55,27 +58,31 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
-__global__ void advance_state_kernel(int32_t* state) {
+__global__ void advance_state_kernel(int32_t* state, const float* skip) {
+  if (skip != nullptr && *skip != 0.f) { state[2] |= 1; return; }   // an invalid step is not counted and stays on record
   state[0] += 1;
   state[1] = (int32_t)asr_fmix32((uint32_t)state[1] + 0x9E3779B9u);
 }
 
 extern "C" int asr_adam_step(float* params, const float* grads, float* m, float* v, long n, const int32_t* state,
-                             const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                             const asr_lr_schedule* lr, float beta1, float beta2, float eps, float grad_scale, const float* skip_flag,
+                             void* stream) {
   ASR_CHECK(params && grads && m && v && state && lr && n > 0, ASR_ERR_ARG, "asr_adam_step: bad argument");
   ASR_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) == 0, ASR_ERR_ARG,
             "asr_adam_step: buffers must be 16-byte aligned");
-  AdamArgs a{params, grads, m, v, n, state, *lr, beta1, beta2, eps, grad_scale};
+  AdamArgs a{params, grads, m, v, n, state, *lr, beta1, beta2, eps, grad_scale, skip_flag};
   const long blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks))), dim3(256), 0, (hipStream_t)stream, a);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
 
-// iterations += 1; seed = fmix32(seed + golden)  -- run once at the end of every training step
-extern "C" int asr_advance_state(int32_t* state, void* stream) {
+// iterations += 1; seed = fmix32(seed + golden)  -- run once at the end of every training step.  skip_flag (optional, device): a
+// non-zero value (a hand-off of a one-launch sweep timed out somewhere in the step, on any rank: the flag travels inside the
+// last gradient bucket) sets state[2] instead - sticky until the host clears it
+extern "C" int asr_advance_state(int32_t* state, const float* skip_flag, void* stream) {
   ASR_CHECK(state, ASR_ERR_ARG, "asr_advance_state: null argument");
-  hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, skip_flag);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

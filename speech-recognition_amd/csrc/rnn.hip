@@ -111,32 +111,19 @@ __device__ __forceinline__ void cell_finish(const FwdDir& d, int H, int b, int j
                                             const float* pre, const float* br, const float* s) {
   // hpm = hp times the recurrent-dropout multiplier (= hp without recurrent dropout): [TF-sem] GRUCell rebinds h_tm1 to the
   // masked value, so the z * h_tm1 carry sees the multiplier; the state carried through a masked step does not
-  float hn, cn = 0.f;
-  if (CELL == CELL_LSTM) {
-    const float ig = sigmoidf_(pre[0] + s[0]), fg = sigmoidf_(pre[1] + s[1]);
-    const float gg = tanhf_(pre[2] + s[2]), og = sigmoidf_(pre[3] + s[3]);
-    const float c2 = fg * cp + ig * gg;
-    hn = og * tanhf_(c2);
-    cn = m ? c2 : cp;
-    if (d.saved) {
-      float* sv = d.saved + (long)b * d.saved_ld + j;
-      sv[0] = ig; sv[H] = fg; sv[2L * H] = gg; sv[3L * H] = og;
-    }
-    if (d.c_out) d.c_out[(long)b * d.c_out_ld + j] = cn;
-  } else if (CELL == CELL_GRU) {
-    const float z = sigmoidf_(pre[0] + s[0] + br[0]);
-    const float r = sigmoidf_(pre[1] + s[1] + br[1]);
-    const float arh = s[3] + br[2];
-    const float hh = tanhf_(pre[2] + s[2] + r * arh);
-    hn = z * hpm + (1.f - z) * hh;
-    if (d.saved) {
-      float* sv = d.saved + (long)b * d.saved_ld + j;
-      sv[0] = z; sv[H] = r; sv[2L * H] = hh; sv[3L * H] = arh;
-    }
-  } else {
-    hn = tanhf_(pre[0] + s[0]);
-    if (d.saved) d.saved[(long)b * d.saved_ld + j] = hn;
+  constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
+  float hn, c2, sv[4];
+  float prel[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NGL = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
+#pragma unroll
+  for (int g = 0; g < NGL; ++g) prel[g] = pre[g];
+  asr_cell_forward<CELL>(prel, s, br, hpm, cp, hn, c2, sv);
+  if (d.saved) {
+    float* o = d.saved + (long)b * d.saved_ld + j;
+#pragma unroll
+    for (int g = 0; g < NSV; ++g) o[(long)g * H] = sv[g];
   }
+  if (CELL == CELL_LSTM && d.c_out) d.c_out[(long)b * d.c_out_ld + j] = m ? c2 : cp;
   if (d.h_out) d.h_out[(long)b * d.h_out_ld + j] = m ? hn : hp;
   if (d.y_out) d.y_out[(long)b * d.y_out_ld + j] = m ? hn : yp;
 }

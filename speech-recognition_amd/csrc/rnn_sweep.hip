@@ -19,6 +19,10 @@
 //             s + 1, whose `s_waitcnt vmcnt(0)` also retires that re-arming store; so by the time any consumer can look
 //             at slot (s + 2) % 4 for h_{s+2} (it must first have seen this workgroup's h_{s+1}) the sentinel - or the
 //             new value - is what memory holds.  Four slots instead of three keep that wait off the critical path.
+// Wave roles: gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave that has just published
+// cannot consume the loads of its next gather before the write-through acknowledgement of that store has come back
+// (measured: +0.34 us per step).  The workgroup therefore has 4 GATHER waves (K split four ways: gather, MFMA, partial sums
+// to LDS; they never store to global memory) and NQ GATE waves (gate math, publish, re-arm, the layer's own outputs).
 // Compared with {value, tag} granules this halves the bytes every step moves across the fabric (16 KB instead of 32 KB
 // per workgroup at H = 256) and the number of load instructions per gather.
 // The buffer is filled with the sentinel before every launch; every spin is bounded: on time-out the workgroup raises
@@ -51,6 +55,8 @@ struct SwArgs {
   unsigned* err;        // per-launch error word (zeroed by the launch)
   float* err_flag;      // caller's sticky flag (set to 1.0f on time-out, never cleared here) or NULL
   int spin_limit;
+  int dbg;              // timing experiments only (ASR_SWEEP_DBG): 2 no wait, 4 no publish
+  int delay;            // s_sleep(2) periods before a gather's first poll
 };
 
 static int g_spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
@@ -63,11 +69,13 @@ __global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero
 }
 
 template <int CELL, int NQ>
-__global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
+__global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) {
   __shared__ float part[2][4][NQ][16 * 17];
   __shared__ int abort_flag;
   const SwDir& d = a.d[blockIdx.z];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool gate_wave = wv < NQ;                       // waves [0, NQ): gate math + publish; waves [NQ, NQ + 4): gather + MFMA
+  const int wave = gate_wave ? 0 : wv - NQ;             // K-split index of a gather wave
   const int li = lane & 15, lq = lane >> 4;
   const int q0 = blockIdx.x * NQ, b0 = blockIdx.y * 16, Q = gridDim.x * NQ;
   const int B = a.B, T = a.T, H = a.H;
@@ -97,8 +105,7 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
   }
   // gate-math ownership: wave n < NQ owns slice q0+n; lane -> (row bi, unit u); recurrent state lives in registers
   const int bi = lane >> 2, u = lane & 3;
-  const bool gate_wave = wave < NQ;
-  const int qn = q0 + (gate_wave ? wave : 0);
+  const int qn = q0 + (gate_wave ? wv : 0);
   const int b = b0 + bi, j = 4 * qn + u;
   const bool live = gate_wave && b < B && j < H;
   float hp = 0.f, cp = 0.f, yp = 0.f, br[3] = {0.f, 0.f, 0.f};
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
       for (int g = 0; g < NG; ++g) pre[g] = pr[(long)g * H];
     }
 
+    if (!gate_wave) {
     // A operand: 16 rows x H of h_{s-1}
     f32x4 av[SW_MAXB];
     if (s == 0) {
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
       const float* p2 = src + (goff[2] >= 0 ? goff[2] : 0);
       const float* p3 = src + (goff[3] >= 0 ? goff[3] : 0);
       int spins = 0;
+      for (int w = 0; w < a.delay; ++w) __builtin_amdgcn_s_sleep(2);
       for (;;) {
         asm volatile(
             "global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
           if (goff[i] >= 0)
             ok = ok && __float_as_uint(av[i].x) != SW_SENT && __float_as_uint(av[i].y) != SW_SENT && __float_as_uint(av[i].z) != SW_SENT &&
                  __float_as_uint(av[i].w) != SW_SENT;
-        if (__all(ok)) break;
+        if (__all(ok) || (a.dbg & 2)) break;
         if (++spins > a.spin_limit || *(volatile int*)&abort_flag) { abort_flag = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -183,11 +192,13 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
 #pragma unroll
       for (int n = 0; n < NQ; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bw[n][i].w, acc[n], 0, 0, 0);
     }
-    float(*pt)[NQ][16 * 17] = part[s & 1];              // double-buffered: a wave may run one step ahead of the gate waves
+    float(*ptw)[NQ][16 * 17] = part[s & 1];             // double-buffered: a gather wave may run one step ahead of the gate waves
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pt[wave][n][(lq * 4 + r) * 17 + li] = acc[n][r];
+      for (int r = 0; r < 4; ++r) ptw[wave][n][(lq * 4 + r) * 17 + li] = acc[n][r];
+    }
+    float(*pt)[NQ][16 * 17] = part[s & 1];
     __syncthreads();
     if (abort_flag) break;
 
@@ -198,27 +209,13 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
       if (live) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          sgv[g] = pt[0][wave][bi * 17 + g * 4 + u] + pt[1][wave][bi * 17 + g * 4 + u] + pt[2][wave][bi * 17 + g * 4 + u] +
-                   pt[3][wave][bi * 17 + g * 4 + u];
-        float hn;
-        if constexpr (CELL == CELL_LSTM) {
-          const float ig = sigmoidf_(pre[0] + sgv[0]), fg = sigmoidf_(pre[1] + sgv[1]);
-          const float gg = tanhf_(pre[2] + sgv[2]), og = sigmoidf_(pre[3] + sgv[3]);
-          const float c2 = fg * cp + ig * gg;
-          hn = og * tanhf_(c2);
-          cn = m ? c2 : cp;
-          sgv[0] = ig; sgv[1] = fg; sgv[2] = gg; sgv[3] = og;
-        } else if constexpr (CELL == CELL_GRU) {
-          const float z = sigmoidf_(pre[0] + sgv[0] + br[0]);
-          const float r = sigmoidf_(pre[1] + sgv[1] + br[1]);
-          const float arh = sgv[3] + br[2];
-          const float hh = tanhf_(pre[2] + sgv[2] + r * arh);
-          hn = z * hp + (1.f - z) * hh;
-          sgv[0] = z; sgv[1] = r; sgv[2] = hh; sgv[3] = arh;
-        } else {
-          hn = tanhf_(pre[0] + sgv[0]);
-          sgv[0] = hn;
-        }
+          sgv[g] = pt[0][wv][bi * 17 + g * 4 + u] + pt[1][wv][bi * 17 + g * 4 + u] + pt[2][wv][bi * 17 + g * 4 + u] +
+                   pt[3][wv][bi * 17 + g * 4 + u];
+        float hn, c2, prel[4] = {0.f, 0.f, 0.f, 0.f}, sums[4] = {sgv[0], sgv[1], sgv[2], sgv[3]};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) prel[g] = pre[g];
+        asr_cell_forward<CELL>(prel, sums, br, hp, cp, hn, c2, sgv);      // sgv <- the activations saved for backward
+        if (CELL == CELL_LSTM) cn = m ? c2 : cp;
         hnew = m ? hn : hp;
         yp = m ? hn : yp;
       }
@@ -229,13 +226,13 @@ __global__ __launch_bounds__(256) void rnn_sweep_fwd_kernel(SwArgs a) {
       pub.y = __shfl_down(hnew, 1, 64);
       pub.z = __shfl_down(hnew, 2, 64);
       pub.w = __shfl_down(hnew, 3, 64);
-      if (u == 0) {
+      if (u == 0 && !(a.dbg & 4)) {
         float* dst = xb + (long)(s & (SW_SLOTS - 1)) * slot_floats + pub_off;
         float* rearm = xb + (long)((s + 2) & (SW_SLOTS - 1)) * slot_floats + pub_off;
         const float sf = __uint_as_float(SW_SENT);
         const f32x4 sent = {sf, sf, sf, sf};
         asm volatile(
-            "s_waitcnt vmcnt(0)\n\t"                      // (no-op after a gather; orders the first steps' stores)
+            "s_waitcnt vmcnt(0)\n\t"                      // retires the re-arming store of the previous step (a step old: no stall)
             "global_store_dwordx4 %0, %1, off sc1\n\t"
             "global_store_dwordx4 %2, %3, off sc1" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
       }
@@ -284,9 +281,9 @@ extern "C" int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int nd
 
 template <int NQ>
 static void sw_launch(int rnn_type, dim3 grid, hipStream_t st, const SwArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_LSTM, NQ>), grid, dim3(256), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_GRU, NQ>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_RNN, NQ>), grid, dim3(256), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_LSTM, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_GRU, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_RNN, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_fwd (rnn.hip), one launch.  ws: asr_rnn_sweep_ws_floats() floats; the uint32 at
@@ -308,6 +305,10 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
   a.err = reinterpret_cast<unsigned*>(ws + xfloats);
   a.err_flag = err_flag;
   a.spin_limit = g_spin_limit;
+  a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
+  // the first poll of a gather cannot succeed before the publish of the step has crossed the fabric (~1 us): polling earlier only
+  // adds traffic in front of it (measured on las_small: 2.38 us per step with no delay, 1.98 with 12 x 128 cycles, 2.15 with 16)
+  a.delay = getenv("ASR_SWEEP_DELAY") ? atoi(getenv("ASR_SWEEP_DELAY")) : 12;
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->y && (!lstm || s->cseq[d]), ASR_ERR_ARG, "asr_rnn_sweep_fwd: null buffer (dir %d)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_fwd: recurrent dropout is not supported (use asr_rnn_seq_fwd)");

@@ -1,0 +1,458 @@
+// One-launch backward-through-time sweep of a whole (Bi)RNN layer on gfx950: the mirror of rnn_sweep.hip.
+//
+// Per step the recurrence needs  dh_{t-1}[16 x H] = ds_t[16 x G*H] x U^T  for every (direction, 16-row batch tile) GROUP, then
+// the element-wise gate gradients ds_{t-1} = f(dh_{t-1}, saved activations).  The product is decomposed in TWO dimensions
+// over a GxG square of workgroups per group (SUMMA style).  With KU = H/G hidden units per "unit group":
+//     workgroup (i, j):  computes ds_t for the units of group i (16 rows x KU units x gates; the gate math is element-wise, so
+//                        the G workgroups of row i repeat it - far cheaper than moving its result),
+//                        multiplies it with its resident [KU gates-columns x KU] block of U^T -> the partial dh of the
+//                        units of group j that is due to the units of group i: one [16 x KU] block,
+//                        PUBLISHES that block once; the G workgroups (j, *) of row j all read it.
+//     To start step t-1 a workgroup gathers the G blocks (i, i') that make up dh for ITS unit group: 16 x H floats (16 KB at
+//     H = 256) - the same volume the forward sweep gathers - while it publishes only 16 x KU floats (2 KB).
+// Splitting the product over output units only (the step kernels, the first persistent kernel) makes every workgroup gather
+// all of ds_t (64 KB per workgroup and step); splitting it over the contraction only makes every workgroup SEND 16 KB in
+// H/4 separate blocks (measured: 3.9 - 5.0 us per step, bound by the write-through stores).  The square needs neither.
+//
+// Hand-off = the forward sweep's: blocks are self-validating (a SENTINEL NaN pattern marks "not written yet"), written with
+// 16-byte write-through stores, polled with `global_load_dwordx4 ... sc1`; 4 slots, step p publishes into slot (p+1) % 4 and
+// the PUBLISHER re-arms the block it wrote two steps earlier (slot (p-1) % 4): having gathered everybody's step p-1 blocks
+// it knows every workgroup has finished step p-1 and with it the gather of slot (p-1) % 4.  All stores to one word come
+// from one wave in program order, with `s_waitcnt vmcnt(0)` once per step between the sentinel and the next value.  (Do
+// NOT let the reader re-arm: two agents storing to the same word race even when one store is issued only after the other
+// was seen retired - an earlier version of this file did that and lost blocks on small, fast shapes.)
+//
+// Wave roles (512 threads).  gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave with
+// write-through stores in flight cannot consume a later load before their acknowledgements are back:
+//   waves 0-3  GATHER + OWNER: poll the G blocks, add them up (registers, then LDS), gate-gradient math of the 16 x KU (row, unit)
+//              pairs, ds to LDS (and, in column j = 0 of the square, to `saved`);
+//   waves 4-7  PUBLISH: multiply ds with the resident block of U^T (contraction split over the waves, summed through LDS),
+//              publish the [16 x KU] block, re-arm the block of two steps ago.  They never load from global memory.
+// The roles hand over through LDS counters (a workgroup barrier would make the gather waves wait for store
+// acknowledgements); LDS buffers are double-buffered by step parity and protected by causality through the exchange
+// (a gather of step p+2 cannot complete before this workgroup's own publish of step p+1).
+// Every spin is bounded; on time-out the error word (who gave up | step << 8) and the caller's sticky flag are raised.
+#include <stdlib.h>
+
+#include "common.h"
+
+#define CELL_LSTM 0
+#define CELL_GRU 1
+#define CELL_RNN 2
+#define SB_SLOTS 4
+#define SB_SENT 0x7FC0DEADu
+
+extern "C" int asr_rnn_sweep_spin_limit(void);
+__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero);
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct SbDir {
+  const float* U; long ldu;
+  float* saved;                 // [B,T,NS*H]: activations in, ds out
+  const float* hseq; const float* cseq;
+  const float* h0; long h0_ld; const float* c0; long c0_ld;
+  const float* dh_last; long dh_last_ld;
+  float* dc;                    // [B,H] in: d/d final c, out: d/d initial c (LSTM)
+  float* dh0; long dh0_ld;
+  int reverse, y_col;
+};
+struct SbArgs {
+  SbDir d[2];
+  int B, T, H, G;               // G x G workgroups per group
+  const uint8_t* mask;
+  const float* dy; long dy_ld;
+  float* xbuf;                  // [groups][SB_SLOTS][G rows][G senders][NT][64 lanes][4]
+  long xbytes;
+  unsigned* err; float* err_flag;
+  int spin_limit;
+  int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish
+  int delay;                    // s_sleep(2) periods before a gather's first poll
+};
+
+// abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
+// gather waves, 3 publish wave waiting for the owner step, 4 publish wave waiting for its contraction partners
+__device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile int* abort_flag, int limit, int code) {
+  for (int i = 0; *c < target; ++i) {
+    if (*abort_flag) return false;
+    if (i > limit) { *abort_flag = code; return false; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+template <int CELL, int NT>      // NT: 16-unit tiles per unit group (KU = 16 NT)
+__global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
+  constexpr int NS = CELL == CELL_RNN ? 1 : 4;                      // saved / ds slots per unit
+  constexpr int NGR = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);   // ds slots that multiply the recurrent kernel
+  constexpr int KU = 16 * NT;                                       // units per unit group
+  constexpr int NL = KU * NGR;                                      // contraction labels (ds columns) of a workgroup
+  constexpr int KP = 4 / NT;                                        // contraction parts: publish wave = (tile, part)
+  constexpr int KPW = NL / 4 / KP;                                  // MFMA k-steps per publish wave (= NT * NT * NGR)
+  constexpr int LD = NL + 4;                                        // padded row of the ds image
+  __shared__ __attribute__((aligned(16))) float red[2][256][4];     // gather partial sums: [parity][thread][4 rows of a position]
+  __shared__ __attribute__((aligned(16))) float dsl[2][16][LD];     // ds of a step: [parity][row][label]
+  __shared__ __attribute__((aligned(16))) float sp[2][KP > 1 ? KP - 1 : 1][NT][256];   // contraction partials of the publish waves
+  __shared__ int abort_flag, g_done, o_done, s_cnt;
+  const SbDir& d = a.d[blockIdx.z];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool go_wave = wv < 4;
+  const int li = lane & 15, lq = lane >> 4;
+  const int G = a.G, gi_ = blockIdx.x / G, gj_ = blockIdx.x % G;    // (i, j): ds of unit group i, partial dh of unit group j
+  const int b0 = blockIdx.y * 16;
+  const int B = a.B, T = a.T, H = a.H;
+  const int group = blockIdx.z * gridDim.y + blockIdx.y;
+  const long blk = (long)NT * 256;                                  // floats per block
+  const long slot_floats = (long)G * G * blk;
+  float* xb = a.xbuf + (long)group * SB_SLOTS * slot_floats;
+  const int lds_limit = a.spin_limit > (1 << 20) ? a.spin_limit : (a.spin_limit << 4);   // LDS polls are ~16x shorter than fabric polls
+  if (tid == 0) { abort_flag = 0; g_done = 0; o_done = 0; s_cnt = 0; }
+  __syncthreads();
+
+  if (go_wave) {
+    // ------------------------------------------------------------------------------------------ GATHER + OWNER
+    // row i of the exchange: G blocks x NT tiles x 64 pieces of 16 bytes; piece f = tid + 256 m -> sender f / (64 NT), position
+    // pos = f % (64 NT) = tid % (64 NT) for every m: (tile nt, lq, li): rows 4lq..4lq+3 of unit 16nt + li
+    constexpr int NPOS = 64 * NT;                                   // positions of a block
+    constexpr int TPP = 256 / NPOS;                                 // threads that share a position (= KP)
+    const int npieces = G * NPOS;
+    const int pos = tid % NPOS, sub = tid / NPOS;                   // this thread finishes rows sub * NT .. sub * NT + NT - 1 of the position
+    const int nt_ = pos >> 6, plq = (pos >> 4) & 3, pli = pos & 15;
+    const int un = 16 * nt_ + pli;                                  // unit inside the group
+    const int j = gi_ * KU + un;                                    // hidden unit
+    const bool writer = gj_ == 0;                                   // column 0 of the square writes the layer's outputs
+    int brow[NT];
+    bool live[NT];
+    float dcv[NT], carry[NT], dirv[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) {
+      brow[r] = b0 + 4 * plq + sub * NT + r;
+      live[r] = brow[r] < B;
+      dcv[r] = (live[r] && CELL == CELL_LSTM) ? d.dc[(long)brow[r] * H + j] : 0.f;
+      carry[r] = 0.f; dirv[r] = 0.f;
+    }
+    const long row_off = (long)gi_ * G * blk;                       // row i inside a slot
+    // element-wise operands are fetched one step ahead: the loads for step p + 1 are issued as soon as the gather of step p has
+    // returned, so they travel while the gate math, the publish and the exchange round of step p run (a wave's loads retire in
+    // order: fetched at the top of their own step they would sit in front of the gather's polls)
+    struct Operands { bool m; float svv[NS], cpv, cov, hpv, dyv; };
+    auto fetch = [&](int p, Operands (&o)[NT]) {
+      const int step = T - 1 - p;
+      const int t = d.reverse ? T - 1 - step : step;
+      const int tp = d.reverse ? t + 1 : t - 1;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        o[r].m = true; o[r].cpv = 0.f; o[r].cov = 0.f; o[r].hpv = 0.f; o[r].dyv = 0.f;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) o[r].svv[g] = 0.f;
+        if (live[r] && p < T) {
+          const long bt = (long)brow[r] * T + t;
+          o[r].m = a.mask ? a.mask[bt] != 0 : true;
+          const float* sv = d.saved + bt * NS * H + j;
+#pragma unroll
+          for (int g = 0; g < NS; ++g) o[r].svv[g] = sv[(long)g * H];
+          o[r].dyv = a.dy[bt * a.dy_ld + d.y_col + j];
+          if (CELL == CELL_LSTM) {
+            o[r].cov = d.cseq[bt * H + j];
+            o[r].cpv = step == 0 ? (d.c0 ? d.c0[(long)brow[r] * d.c0_ld + j] : 0.f) : d.cseq[((long)brow[r] * T + tp) * H + j];
+          }
+          if (CELL == CELL_GRU) o[r].hpv = step == 0 ? (d.h0 ? d.h0[(long)brow[r] * d.h0_ld + j] : 0.f) : d.hseq[((long)brow[r] * T + tp) * H + j];
+        }
+      }
+    };
+    Operands nxt[NT];
+    fetch(0, nxt);
+    // ds of the previous step, written to `saved` one step late: the other workgroups of this row read the same saved
+    // activations, and only when the gather of step p + 1 has returned is it certain that all of them have finished step p
+    float dsp[NT][NS];
+    int t_prev = 0;
+    for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
+      const bool cell = p < T;
+      const int step = T - 1 - p;
+      const int t = cell ? (d.reverse ? T - 1 - step : step) : 0;
+      float sa[NT];
+#pragma unroll
+      for (int r = 0; r < NT; ++r) sa[r] = 0.f;
+      if (p > 0) {
+        const float* src = xb + (long)(p % SB_SLOTS) * slot_floats + row_off;
+        const float* p0 = src + (long)min(tid, npieces - 1) * 4;
+        const float* p1 = src + (long)min(tid + 256, npieces - 1) * 4;
+        const float* p2 = src + (long)min(tid + 512, npieces - 1) * 4;
+        const float* p3 = src + (long)min(tid + 768, npieces - 1) * 4;
+        f32x4 v0, v1, v2, v3;
+        int spins = 0;
+        for (int w = 0; w < a.delay; ++w) __builtin_amdgcn_s_sleep(2);
+        for (;;) {
+          asm volatile(
+              "global_load_dwordx4 %0, %4, off sc1\n\t"
+              "global_load_dwordx4 %1, %5, off sc1\n\t"
+              "global_load_dwordx4 %2, %6, off sc1\n\t"
+              "global_load_dwordx4 %3, %7, off sc1\n\t"
+              "s_waitcnt vmcnt(0)"
+              : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+              : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+              : "memory");
+          auto fresh = [](const f32x4& v) {
+            return __float_as_uint(v.x) != SB_SENT && __float_as_uint(v.y) != SB_SENT && __float_as_uint(v.z) != SB_SENT && __float_as_uint(v.w) != SB_SENT;
+          };
+          bool ok = true;
+          if (tid < npieces) ok = ok && fresh(v0);
+          if (tid + 256 < npieces) ok = ok && fresh(v1);
+          if (tid + 512 < npieces) ok = ok && fresh(v2);
+          if (tid + 768 < npieces) ok = ok && fresh(v3);
+          if (__all(ok) || (a.dbg & 2)) break;
+          if (*(volatile int*)&abort_flag) break;
+          if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (*(volatile int*)&abort_flag) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (tid < npieces) acc += v0;
+        if (tid + 256 < npieces) acc += v1;
+        if (tid + 512 < npieces) acc += v2;
+        if (tid + 768 < npieces) acc += v3;
+        *reinterpret_cast<f32x4*>(&red[p & 1][tid][0]) = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&g_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!sb_wait(&g_done, 4 * p, &abort_flag, lds_limit, 2 | (p << 8))) break;
+        // the TPP threads that share this position hold partial sums over disjoint senders
+#pragma unroll
+        for (int k = 0; k < TPP; ++k)
+#pragma unroll
+          for (int r = 0; r < NT; ++r) sa[r] += red[p & 1][pos + k * NPOS][sub * NT + r];
+      }
+      // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
+      bool m[NT];
+      float svv[NT][NS], cpv[NT], cov[NT], hpv[NT], dyv[NT], addAv[NT];
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        m[r] = nxt[r].m; cpv[r] = nxt[r].cpv; cov[r] = nxt[r].cov; hpv[r] = nxt[r].hpv; dyv[r] = nxt[r].dyv; addAv[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) svv[r][g] = nxt[r].svv[g];
+        if (p == 0 && live[r] && d.dh_last) addAv[r] = d.dh_last[(long)brow[r] * d.dh_last_ld + j];
+      }
+      float ds[NT][4];
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        ds[r][0] = ds[r][1] = ds[r][2] = ds[r][3] = 0.f;
+        const float dh_state = sa[r] + addAv[r] + dirv[r];
+        if (!cell) {
+          if (live[r] && writer && d.dh0) d.dh0[(long)brow[r] * d.dh0_ld + j] = dh_state;
+          continue;
+        }
+        float dir = 0.f;
+        if (live[r]) {
+          if (!m[r]) {
+            dir = dh_state;
+            carry[r] += dyv[r];
+          } else {
+            const float dh = dh_state + dyv[r] + carry[r];
+            carry[r] = 0.f;
+            if constexpr (CELL == CELL_LSTM) {
+              const float ig = svv[r][0], fg = svv[r][1], gg = svv[r][2], og = svv[r][3];
+              const float tc = tanhf_(cov[r]);
+              const float dct = dcv[r] + dh * og * (1.f - tc * tc);
+              ds[r][0] = dct * gg * ig * (1.f - ig);
+              ds[r][1] = dct * cpv[r] * fg * (1.f - fg);
+              ds[r][2] = dct * ig * (1.f - gg * gg);
+              ds[r][3] = dh * tc * og * (1.f - og);
+              dcv[r] = dct * fg;
+            } else if constexpr (CELL == CELL_GRU) {
+              const float z = svv[r][0], rr = svv[r][1], hh = svv[r][2], arh = svv[r][3];
+              const float dahh = dh * (1.f - z) * (1.f - hh * hh);
+              ds[r][0] = dh * (hpv[r] - hh) * z * (1.f - z);
+              ds[r][1] = dahh * arh * rr * (1.f - rr);
+              ds[r][2] = dahh;
+              ds[r][3] = dahh * rr;
+              dir = dh * z;
+            } else {
+              const float hn = svv[r][0];
+              ds[r][0] = dh * (1.f - hn * hn);
+            }
+          }
+          dirv[r] = dir;
+        }
+      }
+      if (!cell) {
+        if (writer) {                                               // the last step's ds (its gather has returned)
+#pragma unroll
+          for (int r = 0; r < NT; ++r)
+            if (live[r]) {
+              float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
+#pragma unroll
+              for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
+            }
+        }
+        break;
+      }
+      // the labelled image of ds for the matrix product: label = gate slot gi * KU + unit  (GRU: gi 2 = slot 3)
+#pragma unroll
+      for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int gi = 0; gi < NGR; ++gi) dsl[p & 1][4 * plq + sub * NT + r][gi * KU + un] = ds[r][CELL == CELL_GRU && gi == 2 ? 3 : gi];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(&o_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // off the critical path from here: ds of the PREVIOUS step to `saved` (safe now: this step's gather has returned), then the
+      // operands of the next step
+      if (writer && p > 0) {
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+          if (live[r]) {
+            float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
+#pragma unroll
+            for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
+          }
+      }
+      fetch(p + 1, nxt);
+      t_prev = t;
+#pragma unroll
+      for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int g = 0; g < NS; ++g) dsp[r][g] = ds[r][g];
+    }
+    if (writer && CELL == CELL_LSTM && !abort_flag) {
+#pragma unroll
+      for (int r = 0; r < NT; ++r)
+        if (live[r]) d.dc[(long)brow[r] * H + j] = dcv[r];
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ PUBLISH
+    const int sw = wv - 4, nt_ = sw % NT, kp = sw / NT;             // output tile, contraction part
+    // B operands: k-step ks of this wave carries label cl = kp * 4 KPW + lq * KPW + ks  <->  (gate slot gi = cl / KU, unit cl % KU of
+    // group i); the lane (li, lq) holds U[unit 16 nt + li of group j][that column].  The labelling is free as long as A agrees.
+    float bwv[KPW];
+#pragma unroll
+    for (int ks = 0; ks < KPW; ++ks) {
+      const int cl = kp * 4 * KPW + lq * KPW + ks, gi = cl / KU, un = cl % KU;
+      bwv[ks] = d.U[(long)(gj_ * KU + 16 * nt_ + li) * d.ldu + (long)gi * H + gi_ * KU + un];   // LSTM i,f,c~,o; GRU z, r, recurrent part of h~
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
+    const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
+    const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
+    for (int p = 0; p < T; ++p) {
+      if (!sb_wait(&o_done, 4 * (p + 1), &abort_flag, lds_limit, 3 | (p << 8))) break;
+      float av[KPW];
+#pragma unroll
+      for (int ks = 0; ks < KPW; ++ks) av[ks] = dsl[p & 1][li][kp * 4 * KPW + lq * KPW + ks];
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KPW; ++ks) {
+        if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bwv[ks], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bwv[ks], acc0, 0, 0, 0);
+      }
+      f32x4 acc = acc0 + acc1;                                       // acc[r] = partial dh[row 4lq + r][unit 16 nt + li of group j]
+      if (KP > 1) {
+        if (kp > 0) *reinterpret_cast<f32x4*>(&sp[p & 1][kp - 1][nt_][lane * 4]) = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kp > 0) continue;
+        if (!sb_wait(&s_cnt, 4 * (p + 1), &abort_flag, lds_limit, 4 | (p << 8))) break;
+#pragma unroll
+        for (int k = 0; k < KP - 1; ++k) acc += *reinterpret_cast<const f32x4*>(&sp[p & 1][k][nt_][lane * 4]);
+      }
+      // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
+      const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
+      if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
+      if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
+    }
+  }
+  __syncthreads();
+  if (abort_flag && tid == 0) {
+    __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// geometry: tiles per unit group (1 or 2) and the side G of the workgroup square of one (direction, batch tile) group
+static bool sb_geometry(int B, int H, int ndir, int* nt, int* G) {
+  if (H <= 0 || H % 16 != 0 || H > 256) return false;
+  const long groups = (long)ndir * asr_cdiv(B, 16);
+  static const int forced = getenv("ASR_SWEEP_BWD_NT") ? atoi(getenv("ASR_SWEEP_BWD_NT")) : 0;
+  for (int t = 1; t <= 2; ++t) {
+    if (H % (16 * t) != 0) continue;
+    if (forced && forced != t && H % (16 * forced) == 0) continue;
+    const int g = H / (16 * t);
+    if (groups * g * g <= 256 || t == 2) {
+      if (groups * g * g > 512) return false;
+      *nt = t; *G = g;
+      return true;
+    }
+  }
+  // H % 32 != 0 and the single-tile square does not fit one workgroup per CU: take it up to two per CU
+  const int g = H / 16;
+  if (groups * g * g > 512) return false;
+  *nt = 1; *G = g;
+  return true;
+}
+
+extern "C" long asr_rnn_sweep_bwd_ws_floats(int B, int H, int ndir) {
+  int nt = 1, G = 1;
+  if (!sb_geometry(B, H, ndir, &nt, &G)) return 32;
+  const long groups = (long)ndir * asr_cdiv(B, 16);
+  return groups * SB_SLOTS * G * G * nt * 256 + 32;
+}
+
+extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, int ndir) {
+  if (rnn_type < 0 || rnn_type > 2 || B <= 0 || T < 2) return 0;
+  if (ndir != 1 && ndir != 2) return 0;
+  int nt, G;
+  return sb_geometry(B, H, ndir, &nt, &G) ? 1 : 0;
+}
+
+template <int NT>
+static void sb_launch(int rnn_type, dim3 grid, hipStream_t st, const SbArgs& a) {
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(512), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(512), 0, st, a);
+}
+
+// Same contract as asr_rnn_seq_bwd (rnn_bwd.hip) in one launch.  gs->direct / gs->dy_carry are not used (those carries
+// live in registers).  ws: asr_rnn_sweep_bwd_ws_floats() floats; the uint32 at ws[ws_floats - 32] is non-zero after
+// the call if a hand-off timed out; err_flag as for asr_rnn_sweep_fwd.
+extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs, float* ws, float* err_flag, void* stream) {
+  ASR_CHECK(s && gs && ws, ASR_ERR_ARG, "asr_rnn_sweep_bwd: null argument");
+  ASR_CHECK(asr_rnn_sweep_bwd_supported(s->rnn_type, s->B, s->T, s->H, s->ndir), ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: shape not supported");
+  const int B = s->B, T = s->T, H = s->H;
+  const bool lstm = s->rnn_type == CELL_LSTM;
+  const int NG = lstm ? 4 : (s->rnn_type == CELL_GRU ? 3 : 1);
+  hipStream_t st = (hipStream_t)stream;
+  int nt = 1, G = 1;
+  sb_geometry(B, H, s->ndir, &nt, &G);
+  const long groups = (long)s->ndir * asr_cdiv(B, 16);
+  const long xfloats = groups * SB_SLOTS * G * G * nt * 256;
+  ASR_CHECK(xfloats * 4 < 2147483647L, ASR_ERR_SHAPE, "asr_rnn_sweep_bwd: exchange buffer beyond 2 GB");
+  SbArgs a{};
+  a.B = B; a.T = T; a.H = H; a.G = G; a.mask = s->mask; a.dy = gs->dy; a.dy_ld = gs->dy_ld;
+  a.xbuf = ws; a.xbytes = xfloats * 4;
+  a.err = reinterpret_cast<unsigned*>(ws + xfloats);
+  a.err_flag = err_flag;
+  a.spin_limit = asr_rnn_sweep_spin_limit();
+  a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
+  // see rnn_sweep.hip; the owner math sits between a gather and the next publish here, so less of the round is dead time
+  // (las_small: 4.04 us per step with no delay, 3.13 with 8 x 128 cycles, 3.33 with 12)
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 8;
+  ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
+  for (int d = 0; d < s->ndir; ++d) {
+    ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
+    SbDir& p = a.d[d];
+    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.saved = s->saved[d]; p.hseq = s->hseq[d]; p.cseq = s->cseq[d];
+    p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
+    p.dh_last = gs->dh_last[d]; p.dh_last_ld = gs->dh_last_ld[d];
+    p.dc = gs->dc[d]; p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];
+    p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
+  }
+  {
+    const size_t n = (size_t)xfloats;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SB_SENT, a.err, 32);
+    ASR_LAUNCH_CHECK();
+  }
+  dim3 grid((unsigned)(G * G), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
+  if (nt == 1) sb_launch<1>(s->rnn_type, grid, st, a);
+  else sb_launch<2>(s->rnn_type, grid, st, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

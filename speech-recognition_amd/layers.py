@@ -223,7 +223,7 @@ class BiRNN:
         if PERSISTENT_RNN and not rdrop and ops.rnn_persist_supported(rt, B, T, H, 2):
             if "persist_ws" not in buf:
                 buf["persist_ws"] = ops.rnn_persist_ws(B, H, 2, x3d.device)
-            ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"])
+            ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"], getattr(self.store, "err_flag", None))
         else:
             ops.rnn_seq_fwd(buf["seq"])
         return buf["y"]
@@ -247,7 +247,7 @@ class BiRNN:
             if "persist_bwd_ws" not in buf:
                 buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
             pws = buf["persist_bwd_ws"]
-        ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws)
+        ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
         x2d = buf["x3d"].reshape(B * T, self.Din)
         g, p = self.store.g, self.store.p
 

@@ -10,6 +10,7 @@ the network output collapses to the Dense bias (could not be co
 TF).  "intended" (default) uses the product of the time strides; "reference_compat" reproduces the
 all-False mask.
 """
+import random
 from collections import OrderedDict
 from typing import List, Optional
 
@@ -97,7 +98,7 @@ class DeepSpeech2(ModelProto):
         fc, rest, bufs = self.param_shapes(frequency_dim, feature_dim)
         shapes = OrderedDict(list(fc.items()) + list(rest.items()))
         self.store = ParamStore(shapes, [list(fc), list(rest)], self.device)
-        gen = torch.Generator().manual_seed(self.init_seed if self.init_seed is not None else 0)
+        gen = torch.Generator().manual_seed(self.init_seed if self.init_seed is not None else random.randrange(2 ** 31))
         self.store.load({n: init_value(n, s, gen, self.rt) for n, s in shapes.items()})
         self.buffers = {n: init_value(n, s, gen).to(self.device) for n, s in bufs.items()}
         _, Fo = self.conv_out_dims(10 ** 6, frequency_dim)

@@ -5,6 +5,7 @@ is a hand-written gfx950 kernel inside libasr_mi355x.so.  All wrappers launch on
 ``torch.cuda.current_stream()`` and never synchronise.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -404,26 +405,33 @@ def rnn_seq_fwd(seq):
 
 
 def rnn_persist_supported(rnn_type, B, T, H, ndir=2):
-    return bool(lib().asr_rnn_persist_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+    """True when the one-launch forward sweep (rnn_sweep.hip) takes this layer."""
+    return bool(lib().asr_rnn_sweep_supported(rnn_type_id(rnn_type), B, T, H, ndir))
 
 
 def rnn_persist_ws(B, H, ndir=2, device="cuda"):
-    return torch.zeros(int(lib().asr_rnn_persist_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
+    return torch.zeros(int(lib().asr_rnn_sweep_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
 
 
-def rnn_seq_fwd_persist(seq, ws):
-    """One persistent launch for the whole sequence; ws from rnn_persist_ws (error word = ws[-32] bits)."""
-    check(lib().asr_rnn_seq_fwd_persist(C.byref(seq), _p(ws), _stream()))
+def rnn_seq_fwd_persist(seq, ws, err_flag=None):
+    """One launch for the whole sequence; ws from rnn_persist_ws (error word = ws[-32] bits); err_flag: optional device
+    float that is set to 1.0 when a hand-off times out (sticky: the library never clears it)."""
+    check(lib().asr_rnn_sweep_fwd(C.byref(seq), _p(ws), _p(err_flag), _stream()))
 
 
-def rnn_persist_error(ws) -> bool:
-    """True if a hand-off of the last persistent launch timed out (synchronises)."""
-    return bool(ws[-32:].view(torch.int32)[0].item() != 0)
+def rnn_persist_error(ws) -> int:
+    """Non-zero if a hand-off of the last one-launch sweep timed out (synchronises): (who gave up | step << 8)."""
+    return int(ws[-32:].view(torch.int32)[0].item())
 
 
-def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None):
+def rnn_sweep_set_spin_limit(polls: int):
+    """Polls before a hand-off of the one-launch sweeps gives up (tests force time-outs with 0)."""
+    lib().asr_rnn_sweep_set_spin_limit(int(polls))
+
+
+def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None, err_flag=None):
     """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0.
-    persist_ws: scratch from rnn_persist_bwd_ws -> one persistent launch instead of one per step."""
+    persist_ws: scratch from rnn_persist_bwd_ws -> the one-launch sweep instead of one launch per step."""
     g = _lib.RnnSeqGrad()
     g.dy = dy.data_ptr()
     g.dy_ld = dy.stride(1)
@@ -435,17 +443,17 @@ def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None):
     g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
     g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
     if persist_ws is not None:
-        check(lib().asr_rnn_seq_bwd_persist(C.byref(seq), C.byref(g), _p(persist_ws), _stream()))
+        check(lib().asr_rnn_sweep_bwd(C.byref(seq), C.byref(g), _p(persist_ws), _p(err_flag), _stream()))
     else:
         check(lib().asr_rnn_seq_bwd(C.byref(seq), C.byref(g), _stream()))
 
 
 def rnn_persist_bwd_supported(rnn_type, B, T, H, ndir=2):
-    return bool(lib().asr_rnn_persist_bwd_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+    return bool(lib().asr_rnn_sweep_bwd_supported(rnn_type_id(rnn_type), B, T, H, ndir))
 
 
 def rnn_persist_bwd_ws(B, H, ndir=2, device="cuda"):
-    return torch.zeros(int(lib().asr_rnn_persist_bwd_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
+    return torch.zeros(int(lib().asr_rnn_sweep_bwd_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
 
 
 def back_src(D, W, rnn_type, H, kind, drop=None):
@@ -681,13 +689,14 @@ def lr_schedule(total_steps, max_learning_rate, min_learning_rate, warmup_rate=0
     return s
 
 
-def adam_step(params, grads, m, v, state, sched, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+def adam_step(params, grads, m, v, state, sched, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, skip_flag=None):
+    """skip_flag: optional device float; non-zero = the step's gradients are invalid, nothing is updated."""
     check(lib().asr_adam_step(_p(params), _p(grads), _p(m), _p(v), params.numel(), _p(state), C.byref(sched), beta1, beta2,
-                              eps, grad_scale, _stream()))
+                              eps, grad_scale, _p(skip_flag), _stream()))
 
 
-def advance_state(state):
-    check(lib().asr_advance_state(_p(state), _stream()))
+def advance_state(state, skip_flag=None):
+    check(lib().asr_advance_state(_p(state), _p(skip_flag), _stream()))
 
 
 def ctc_workspace_floats(B, T, L):

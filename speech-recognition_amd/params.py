@@ -36,12 +36,19 @@ class ParamStore:
                 self.offsets[n] = off
                 off += _align(math.prod(self.shapes[n]))
             self.bucket_ranges.append((start, off))
+        # one extra cell at the end of the LAST bucket: the step's error flag.  The one-launch recurrent sweeps write 1.0 into
+        # the gradient buffer's copy when a hand-off times out; it is zeroed with the gradients, summed across ranks with the last
+        # bucket (so every replica sees it), and Adam / advance_state skip the step when it is non-zero.
+        self.err_off = off
+        off += 4
+        self.bucket_ranges[-1] = (self.bucket_ranges[-1][0], off)
         self.numel = off
         self.device = device
         self.flat = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
         self.adam_m = torch.zeros(off, device=device, dtype=torch.float32)
         self.adam_v = torch.zeros(off, device=device, dtype=torch.float32)
+        self.err_flag = self.grad[self.err_off:self.err_off + 1]
         self.p = {n: self._view(self.flat, n) for n in self.shapes}
         self.g = {n: self._view(self.grad, n) for n in self.shapes}
         self.flat16 = None          # bf16 image of `flat` (mixed precision), refreshed once per optimizer step

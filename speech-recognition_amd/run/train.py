@@ -88,12 +88,22 @@ def main(cfg: TrainConfig, **extra):
     opts = {**EXTRA_FLAGS, **extra}
     logger = get_logger("train")
 
-    if cfg.seed:
-        set_random_seed(cfg.seed)
-        logger.info(f"[+] Set random seed to {cfg.seed}")
-
     strategy = get_device_strategy(cfg.device)          # RuntimeError unless --device GPU on an MI355X
     rank, world = strategy.rank, strategy.world_size
+
+    # train.py:88-90 seeds only when --seed is given.  Under data parallelism every rank must nevertheless draw the SAME
+    # shuffles (each slices its share out of one global batch), so without --seed rank 0 draws a seed for all of them.
+    seed = cfg.seed
+    if seed is None and world > 1:
+        import random
+
+        import torch.distributed as dist
+        box = [random.randrange(2 ** 31)]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
+    if seed is not None:
+        set_random_seed(seed)
+        logger.info(f"[+] Set random seed to {seed}")
 
     # Copy config file
     if rank == 0:
@@ -152,7 +162,7 @@ def main(cfg: TrainConfig, **extra):
 
     # Model Initialize
     logger.info("[+] Model Initialize")
-    model = cfg.model_config.create_model()
+    model = cfg.model_config.create_model(seed=seed)
     model.build(dc.frequency_dim, dc.feature_dim)
     if rank == 0:
         model.summary(print_fn=logger.info)
@@ -166,7 +176,7 @@ def main(cfg: TrainConfig, **extra):
     logger.info("[+] Model compile")
     schedule = LRScheduler(cfg.total_steps, cfg.learning_rate, cfg.min_learning_rate, cfg.warmup_rate, cfg.warmup_steps, cfg.offset_steps)
     trainer = TrainStep(model, schedule, frontend=frontend, eval_frontend=eval_frontend, strategy=strategy,
-                        use_graph=not opts["no_hip_graph"])
+                        use_graph=not opts["no_hip_graph"])      # broadcasts rank 0's weights / moments / state to every replica
 
     # Shuffle & Make train example
     train_dataset = train_dataset.map(model.make_example)
@@ -182,7 +192,7 @@ def main(cfg: TrainConfig, **extra):
     # Padded Batch.  Audio is padded in samples here (or stored frames with --use-tfrecord); the frame axis of
     # get_batching_shape is fixed only on TPU in the reference, so the GPU path always pads to the batch maximum.
     logger.info("[+] Pad Input data")
-    train_dataset = (train_dataset.shuffle(cfg.shuffle_buffer_size, seed=cfg.seed)
+    train_dataset = (train_dataset.shuffle(cfg.shuffle_buffer_size, seed=seed)
                      .padded_batch(cfg.batch_size, with_lengths=True).prefetch(4))
     dev_dataset = dev_dataset.padded_batch(cfg.dev_batch_size, with_lengths=True)
 

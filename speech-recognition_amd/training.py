@@ -58,6 +58,31 @@ class GradientExchange:
         self._pending = []
 
 
+def sync_replicas(model, world: int, group=None, src: int = 0):
+    """Make every data-parallel replica start from rank `src`'s state (tf.distribute.MirroredStrategy creates mirrored,
+    identical variables - utils.py:148-149; here every rank builds its own model, so without this they would differ whenever
+    no --seed is given): parameters, Adam moments, BatchNorm moving statistics, the device state words (step counter, dropout
+    seed) and the host RNG of the teacher-forcing coin.  Gradients alone are exchanged afterwards, so replicas that start
+    equal stay equal.  Works on whatever device the tensors live on (RCCL for GPU tensors under "nccl", gloo in the tests)."""
+    if world <= 1:
+        return
+    import random
+
+    import torch.distributed as dist
+    st = model.store
+    for t in (st.flat, st.adam_m, st.adam_v):
+        dist.broadcast(t, src=src, group=group)
+    for name in sorted(getattr(model, "buffers", {})):
+        dist.broadcast(model.buffers[name], src=src, group=group)
+    dist.broadcast(model.state, src=src, group=group)
+    seed = [random.randrange(2 ** 31)]
+    dist.broadcast_object_list(seed, src=src, group=group)
+    if hasattr(model, "_py_rng"):
+        model._py_rng = random.Random(seed[0])
+    if hasattr(model, "weights_changed"):
+        model.weights_changed()
+
+
 class TrainStep:
     def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
                  beta1=0.9, beta2=0.999, eps=1e-7, eval_frontend=None):
@@ -78,6 +103,19 @@ class TrainStep:
         self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
         self.exchange = GradientExchange(self.world, self.group, self.stream)
         self.iterations = 0
+        self._replicas_synced = False
+        if getattr(model, "built", False):
+            self.sync_replicas()
+
+    def sync_replicas(self):
+        """Broadcast rank 0's model state to every replica (see training.sync_replicas); called once the model is built, and
+        again by the caller after anything that changes one replica only (load_weights on rank 0, ...)."""
+        if self.world > 1:
+            self.synchronize()
+            sync_replicas(self.model, self.world, self.group)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        self._replicas_synced = True
 
     # ------------------------------------------------------------------------------------------ buffers
     def _ctx(self, audio, n_samples, tokens):
@@ -102,6 +140,8 @@ class TrainStep:
             c["feats"] = c["audio"]
         f = c["feats"]
         self.model._ensure_built(f.shape[2], f.shape[3])
+        if not self._replicas_synced:                      # the model was built lazily on this first batch
+            self.sync_replicas()
         c["ws"], c["labels"] = self.model.train_workspace(B, f.shape[1], tokens.shape[1])
         self._shapes[key] = c
         return c
@@ -119,8 +159,11 @@ class TrainStep:
 
     def _update(self):
         m = self.model
-        ops.adam_step(m.store.flat, m.store.grad, m.store.adam_m, m.store.adam_v, m.state, self.sched, self.beta1, self.beta2, self.eps)
-        ops.advance_state(m.state)
+        # store.err_flag (inside the last gradient bucket, so already summed over the replicas): a recurrent sweep timed out somewhere
+        # in this step - the update is skipped on every rank and the sticky error word state[2] is set instead
+        ops.adam_step(m.store.flat, m.store.grad, m.store.adam_m, m.store.adam_v, m.state, self.sched, self.beta1, self.beta2, self.eps,
+                      skip_flag=m.store.err_flag)
+        ops.advance_state(m.state, m.store.err_flag)
 
     def _segments(self, c, teacher):
         """The step as a list of stream-ordered callables; gradient bucket k is complete after
@@ -206,13 +249,20 @@ class TrainStep:
             self.exchange.comm_stream.synchronize()
 
     def read_stats(self, ws):
-        """Host copy of [loss, #correct, #kept] (synchronises).  Also checks the error words of the
-        persistent recurrent kernels: a timed-out hand-off invalidates the step and is never silent."""
+        """Host copy of [loss, #correct, #kept] (synchronises).  Also checks the model's sticky error word: if a hand-off of a
+        one-launch recurrent sweep timed out in ANY step since the last check (on any rank), those steps were skipped (parameters,
+        moments and the step counter untouched) and this raises - a time-out is never silent and never trains on garbage."""
         self.synchronize()
-        for lw in getattr(ws, "layers", []):
-            for key in ("persist_ws", "persist_bwd_ws"):
-                pws = lw["rnn"].get(key) if isinstance(lw, dict) and "rnn" in lw else None
-                if pws is not None and ops.rnn_persist_error(pws):
-                    raise RuntimeError("persistent recurrent kernel: an inter-workgroup hand-off timed out "
-                                       "(GPU shared with another job?); rerun with ASR_PERSISTENT_RNN=0")
+        st = self.model.state.cpu()
+        if int(st[2]) != 0:
+            self.model.state[2] = 0
+            detail = ""
+            for lw in getattr(ws, "layers", []):
+                for key in ("persist_ws", "persist_bwd_ws"):
+                    pws = lw["rnn"].get(key) if isinstance(lw, dict) and "rnn" in lw else None
+                    code = ops.rnn_persist_error(pws) if pws is not None else 0
+                    if code:
+                        detail = f" (last launch: {key} gave up with code {code & 255} at step {code >> 8})"
+            raise RuntimeError("one-launch recurrent sweep: an inter-workgroup hand-off timed out (GPU shared with another job?); the "
+                               "affected training steps were skipped" + detail + "; rerun with ASR_PERSISTENT_RNN=0")
         return [float(v) for v in ws.stats[:3].cpu()]

@@ -65,3 +65,66 @@ def test_single_replica_exchange_is_a_no_op():
     ex.reduce_async(t)
     ex.wait()
     assert torch.equal(t, torch.arange(5.0))
+
+
+# ---------------------------------------------------------------------------------------------- replica synchronisation
+class _FakeModel:
+    """The parts of a model that training.sync_replicas touches, on the CPU, initialised differently on every rank."""
+
+    def __init__(self, rank):
+        import random
+        from collections import OrderedDict
+
+        from speech_recognition_amd.params import ParamStore
+        g = torch.Generator().manual_seed(1000 + rank)
+        shapes = OrderedDict([("a/w", (5, 3)), ("a/b", (3,)), ("b/w", (4, 4))])
+        self.store = ParamStore(shapes, [["a/w", "a/b"], ["b/w"]], device="cpu")
+        for t in (self.store.flat, self.store.adam_m, self.store.adam_v):
+            t.copy_(torch.randn(t.shape, generator=g))
+        self.buffers = {"bn/moving_mean": torch.randn(4, generator=g), "bn/moving_variance": torch.rand(4, generator=g)}
+        self.state = torch.tensor([rank * 7, 100 + rank, 0, 0], dtype=torch.int32)
+        self._py_rng = random.Random(rank)
+        self.changed = 0
+
+    def weights_changed(self):
+        self.changed += 1
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import speech_recognition_amd  # noqa: F401
+        from speech_recognition_amd.training import sync_replicas
+        m = _FakeModel(rank)
+        sync_replicas(m, world)
+        q.put((rank, m.store.flat.clone().numpy(), m.store.adam_m.clone().numpy(), m.store.adam_v.clone().numpy(),
+               {k: v.clone().numpy() for k, v in m.buffers.items()}, m.state.clone().numpy(), [m._py_rng.random() for _ in range(3)], m.changed))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sync_replicas_gives_every_rank_rank0_state():
+    """replicas built without a seed start from different weights; TrainStep broadcasts rank 0's parameters,
+    Adam moments, BatchNorm statistics, device state words and the teacher-forcing RNG before the first step."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=90) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(30)
+    r0, r1 = res
+    ref = _FakeModel(0)
+    assert np.array_equal(r0[1], ref.store.flat.numpy()) and np.array_equal(r0[5], ref.state.numpy())    # rank 0 is the source
+    for i in (1, 2, 3, 5):
+        assert np.array_equal(r0[i], r1[i]), i
+    for k in r0[4]:
+        assert np.array_equal(r0[4][k], r1[4][k]), k
+    assert r0[6] == r1[6]                 # the same teacher-forcing coins from here on
+    assert r0[7] == r1[7] == 1            # packed weight images are refreshed

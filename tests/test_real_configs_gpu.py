@@ -12,7 +12,8 @@ parity through the kernels the benchmark actually times:
 
 Tolerances (f32 kernels against a float64 oracle; the loss bound is north_star's): loss 1e-3 absolute, logits 1e-3 of
 their range, gradients 5e-3 of each tensor's largest entry at full size (f32 sums over ~10^5 terms), 2e-3 on the small
-models; mixed precision: bf16 operand rounding, 5e-2.
+models; las_large (2048-wide ReLU(BN) layers): relative L2 5e-3 with the entry-wise bound at 5e-2 (see _check_grads);
+mixed precision: bf16 operand rounding, L2 6e-2.
 """
 import os
 
@@ -89,9 +90,13 @@ def _leaves(model):
     return {k: v.clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k, v in vals.items()}
 
 
-def _check_grads(model, leaves, tol, min_named=()):
-    """Every parameter gradient against autograd on the oracle, normalised by the tensor's largest reference entry; all
-    offenders are listed (not only the first)."""
+def _check_grads(model, leaves, tol, min_named=(), tol_l2=None):
+    """Every parameter gradient against autograd on the oracle.  Two norms per tensor: the largest entry error divided by the
+    largest reference entry (`tol`), and - when tol_l2 is given - the relative L2 error.  The L2 bound is the tight one at
+    full model size: ReLU(BatchNorm(.)) is not differentiable at 0, and among the ~10^6 pre-activations of a layer a
+    handful lie within f32 rounding of 0, so their derivative legitimately differs between an f32 and an f64 forward
+    pass; each such element moves a few gradient entries by up to one summand (a few % of the largest entry at 10^3
+    rows) while the L2 error stays at rounding level - whereas a wrong kernel moves both.  All offenders are listed."""
     worst, worst_name, bad = 0.0, None, []
     grads = model.store.grads()
     for n in min_named:
@@ -100,13 +105,15 @@ def _check_grads(model, leaves, tol, min_named=()):
         ref = leaves[n].grad
         assert ref is not None, n
         assert bool(torch.isfinite(gten).all()), n
+        diff = gten.double().cpu() - ref
         scale = max(float(ref.abs().max()), 1e-4)
-        err = float((gten.double().cpu() - ref).abs().max()) / scale
+        err = float(diff.abs().max()) / scale
+        l2 = float(diff.norm()) / max(float(ref.norm()), 1e-4 * ref.numel() ** 0.5)
         if err > worst:
             worst, worst_name = err, n
-        if not err < tol:
-            bad.append(f"{n}: {err:.2e} (max |ref| {float(ref.abs().max()):.2e})")
-    assert not bad, f"gradients beyond the normalised tolerance {tol:.0e}: " + "; ".join(bad)
+        if not err < tol or (tol_l2 is not None and not l2 < tol_l2):
+            bad.append(f"{n}: max {err:.2e} l2 {l2:.2e} (max |ref| {float(ref.abs().max()):.2e})")
+    assert not bad, f"gradients beyond the tolerances (max-norm {tol:.0e}, l2 {tol_l2}): " + "; ".join(bad)
     return worst, worst_name
 
 
@@ -286,8 +293,10 @@ def test_las_large_yml_training_step_wide_kernels(mixed):
         torch.cuda.synchronize()
         assert abs(float(ws.stats[0]) - float(loss_r.detach())) < (3e-2 if mixed else 1e-3), (float(ws.stats[0]), float(loss_r))
         assert not any(f or b for f, b in _persistent_layers(ws)), "H = 1024 is beyond the persistent kernels: the step kernels run"
-        _check_grads(model, leaves, 8e-2 if mixed else 5e-3, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
-                                                               "attend_and_speller/decoder_layers/1/cell/kernel"))
+        # f32: L2 at rounding level, entry-wise bound loosened for the ReLU kinks (see _check_grads); mixed: bf16 operand rounding
+        _check_grads(model, leaves, 2e-1 if mixed else 5e-2, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
+                                                               "attend_and_speller/decoder_layers/1/cell/kernel"),
+                     tol_l2=6e-2 if mixed else 5e-3)
     finally:
         ops.set_mixed_precision(False)
 

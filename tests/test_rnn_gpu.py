@@ -148,6 +148,77 @@ def test_persistent_backward_matches_step_kernels(rt, B, T, D, H, masked):
             assert_close(res[1][0][d][k], res[0][0][d][k], 2e-5, k)
 
 
+@pytest.mark.parametrize("rt,B,T,D,H", PERSIST_CASES + [("gru", 18, 30, 5, 128), ("lstm", 33, 21, 4, 64)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_persistent_sweeps_match_oracle_autograd(rt, B, T, D, H, masked):
+    """The one-launch forward AND backward sweeps against the float64 oracle directly (torch.autograd through oracle.layers.birnn):
+    outputs, final states, dx, dW, dU, db, dh0, dc0 - arbitrary masks with a fully masked row, chained initial states, gradients
+    flowing into both the output sequence and the final states.  Tolerances: f32 recurrences over up to 249 steps against
+    float64 - 1e-4 of the largest entry forward, 2e-4 backward (the same bounds the per-step kernels are held to, x2 for the
+    longer sequences)."""
+    g = torch.Generator().manual_seed(7 * B + T + H)
+    fwd, bwd = make_params(rt, D, H, g, 0.3 if H < 100 else 0.08)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = (torch.randn(B, T, generator=g) > -0.3) if masked else torch.ones(B, T, dtype=torch.bool)
+    if masked:
+        mask[0] = False
+        mask[-1, : T // 2] = False
+    nst = 2 if rt == "lstm" else 1
+    init = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.5 for _ in range(2 * nst)] if masked else None
+    leaves = [t.clone().requires_grad_(True) for p in (fwd, bwd) for t in p]
+    xl = x.clone().requires_grad_(True)
+    il = [t.clone().requires_grad_(True) for t in init] if init else None
+    out, *states = L.birnn(rt, xl, mask, tuple(leaves[:3]), tuple(leaves[3:]), il)
+    R = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    S = [torch.randn(s.shape, generator=g, dtype=torch.float64) for s in states]
+    ((out * R).sum() + sum((s * w).sum() for s, w in zip(states, S))).backward()
+
+    hip = HipBiRNN(rt, x, mask if masked else None, fwd, bwd, init)
+    y, hstates = hip.forward(persistent=True)
+    assert_close(y, out, 1e-4, "outputs")
+    for i, (a, b_) in enumerate(zip(hstates, states)):
+        assert_close(a, b_, 1e-4, f"state {i}")
+    grads = hip.backward(R, S, persistent=True)
+    assert_close(grads[0]["dx"] + grads[1]["dx"], xl.grad, 2e-4, "dx")
+    for d in range(2):
+        W, U, b = leaves[3 * d: 3 * d + 3]
+        assert_close(grads[d]["dW"], W.grad, 2e-4, f"dW[{d}]")
+        assert_close(grads[d]["dU"], U.grad, 2e-4, f"dU[{d}]")
+        assert_close(grads[d]["db"], b.grad, 2e-4, f"db[{d}]")
+        if init:
+            assert_close(grads[d]["dh0"], il[d * nst].grad, 2e-4, f"dh0[{d}]")
+            if rt == "lstm":
+                assert_close(grads[d]["dc0"], il[d * nst + 1].grad, 2e-4, f"dc0[{d}]")
+
+
+def test_sweep_timeout_raises_the_error_words_and_drains():
+    """spin limit 0: every gather gives up at once - the launches must still terminate, set the per-launch error word and the
+    caller's sticky flag, and a following launch with the normal limit must be clean again."""
+    from speech_recognition_amd import ops
+    rt, B, T, D, H = "lstm", 32, 12, 4, 64
+    g = torch.Generator().manual_seed(5)
+    fwd, bwd = make_params(rt, D, H, g, 0.1)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    hip = HipBiRNN(rt, x, None, fwd, bwd, None)
+    ws = ops.rnn_persist_ws(B, H, 2)
+    flag = torch.zeros(1, device="cuda")
+    ops.rnn_sweep_set_spin_limit(0)
+    try:
+        ops.rnn_seq_fwd_persist(hip.seq, ws, flag)
+        torch.cuda.synchronize()
+        assert ops.rnn_persist_error(ws) and float(flag[0]) == 1.0
+    finally:
+        ops.rnn_sweep_set_spin_limit(1 << 18)
+    ops.rnn_seq_fwd_persist(hip.seq, ws, flag)
+    torch.cuda.synchronize()
+    assert not ops.rnn_persist_error(ws)
+    assert float(flag[0]) == 1.0, "the sticky flag is only ever cleared by its owner"
+    y_ok = hip.y.clone()
+    hip2 = HipBiRNN(rt, x, None, fwd, bwd, None)
+    hip2.forward(persistent=False)
+    assert torch.equal(y_ok, hip2.y)
+
+
 @pytest.mark.parametrize("rt,B,T,D,H", [("lstm", 40, 5, 8, 512), ("gru", 64, 4, 6, 516)])
 def test_wide_step_kernels_mixed_precision(rt, B, T, D, H):
     """--mixed-precision on the wide step kernels (H >= 512, several batch tiles): bf16 weight images and bf16-rounded
