@@ -281,6 +281,11 @@ int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fw
 /* dst[i] = bf16(src[i]), round to nearest even: the bf16 weight images above (train.py:62-66 --mixed-precision:
  * with them the wide step kernels multiply bf16 weights by bf16-rounded states on the bf16 MFMA, f32 accumulation) */
 int asr_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* dst[i] = float(src[i]) for a bf16 array (gradient buckets that were all-reduced as bf16) */
+int asr_bf16_to_f32(const void* src, float* dst, long n, void* stream);
+/* Diagnostic: `blocks` workgroups of `threads` threads that do nothing for `microseconds` (<= 2 s, bounded by the real-time
+ * counter): stands in for a foreign kernel (an RCCL channel) holding compute units while the one-launch sweeps run. */
+int asr_debug_occupy(int blocks, int threads, int microseconds, void* stream);
 
 /* Backward of one cell step.  The gradient handed from step to step is ds, the gradient wrt the gate
  * sums ([B, NS*H], written over the saved activations).  A source describes one consumer of this

@@ -126,6 +126,8 @@ SIGNATURES = {
     "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
     "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
     "asr_f32_to_bf16": (C.c_int, [_P, _P, c_long, _P]),
+    "asr_bf16_to_f32": (C.c_int, [_P, _P, c_long, _P]),
+    "asr_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),

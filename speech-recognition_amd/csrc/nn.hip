@@ -389,3 +389,45 @@ extern "C" int asr_f32_to_bf16(const float* src, void* dst, long n, void* stream
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
+
+// dst[i] = float(src[i]): the way back for gradient buckets that crossed the fabric as bf16 (training.GradientExchange)
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + i);
+      *reinterpret_cast<float4*>(dst + i) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    } else {
+      for (long k = i; k < n; ++k) dst[k] = (float)src[k];
+    }
+  }
+}
+
+extern "C" int asr_bf16_to_f32(const void* src, float* dst, long n, void* stream) {
+  ASR_CHECK(src && dst, ASR_ERR_ARG, "asr_bf16_to_f32: null argument");
+  ASR_CHECK(n > 0, ASR_ERR_SHAPE, "asr_bf16_to_f32: n must be > 0");
+  ASR_CHECK((((uintptr_t)dst & 15) == 0) && (((uintptr_t)src & 7) == 0), ASR_ERR_ARG, "asr_bf16_to_f32: dst must be 16-byte and src 8-byte aligned");
+  const long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const __bf16*>(src), dst, n);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ diagnostics
+// Keeps `blocks` workgroups of `threads` threads busy for `microseconds` (bounded by the 100 MHz real-time counter, so it
+// always ends): a stand-in for a foreign kernel (an RCCL channel) that holds compute units while the one-launch sweeps run.
+__global__ void occupy_kernel(long ticks, unsigned* sink) {
+  const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+  unsigned spins = 0;
+  while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); ++spins; }
+  if (sink != nullptr && threadIdx.x == 0 && blockIdx.x == 0) *sink = spins;
+}
+
+extern "C" int asr_debug_occupy(int blocks, int threads, int microseconds, void* stream) {
+  ASR_CHECK(blocks > 0 && threads > 0 && threads <= 1024 && microseconds >= 0 && microseconds <= 2000000, ASR_ERR_ARG, "asr_debug_occupy: bad argument");
+  hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream, (long)microseconds * 100, nullptr);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

@@ -257,6 +257,29 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
   }
 }
 
+// Workgroups of `kernel` the chip can hold at once (occupancy API x compute units), or -1 when no device is visible (the CPU-only
+// build check).  The API is known to answer one block per CU too many near the SGPR limits (MI355X_MICROARCH.md, residency):
+// the answer is capped at 4 per CU, and callers keep a quarter of it free for whatever else runs beside the sweep (RCCL).
+long asr_sweep_capacity(const void* kernel, int threads) {
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return -1; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return (long)(per < 4 ? per : 4) * cus;
+}
+
+template <int NQ>
+static long sw_fwd_capacity(int rnn_type) {
+  static long cache[3] = {0, 0, 0};                               // 0 = not asked yet
+  if (cache[rnn_type] == 0) {
+    const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_LSTM, NQ>)
+                  : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_GRU, NQ>)
+                                         : reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_RNN, NQ>);
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + NQ));
+  }
+  return cache[rnn_type];
+}
+
 static int sw_nq(int B, int H, int ndir) {
   // slices per workgroup: 1 (one workgroup per 4 units, shortest matrix phase) unless that grid would not fit the chip
   static const int forced = getenv("ASR_SWEEP_NQ") ? atoi(getenv("ASR_SWEEP_NQ")) : 0;
@@ -276,7 +299,12 @@ extern "C" int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int nd
   if (rnn_type < 0 || rnn_type > 2 || B <= 0 || T < 2 || H <= 0 || H % 16 != 0 || H > 64 * SW_MAXB) return 0;
   if (ndir != 1 && ndir != 2) return 0;
   const long wgs = (long)(H / 4) * asr_cdiv(B, 16) * ndir;
-  return wgs <= 512 ? 1 : 0;                                             // two slices per workgroup above 256
+  if (wgs > 512) return 0;                                               // two slices per workgroup above 256
+  // every workgroup of the launch has to be resident at once (they wait for each other): ask the device, keep a quarter free
+  const int nq = sw_nq(B, H, ndir);
+  const long cap = nq == 1 ? sw_fwd_capacity<1>(rnn_type) : sw_fwd_capacity<2>(rnn_type);
+  if (cap >= 0 && (wgs / nq) * 4 > cap * 3) return 0;
+  return 1;
 }
 
 template <int NQ>

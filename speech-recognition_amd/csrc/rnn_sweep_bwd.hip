@@ -43,6 +43,7 @@
 #define SB_SENT 0x7FC0DEADu
 
 extern "C" int asr_rnn_sweep_spin_limit(void);
+long asr_sweep_capacity(const void* kernel, int threads);
 __global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -394,11 +395,28 @@ extern "C" long asr_rnn_sweep_bwd_ws_floats(int B, int H, int ndir) {
   return groups * SB_SLOTS * G * G * nt * 256 + 32;
 }
 
+template <int NT>
+static long sb_capacity(int rnn_type) {
+  static long cache[3] = {0, 0, 0};
+  if (cache[rnn_type] == 0) {
+    const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_LSTM, NT>)
+                  : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_GRU, NT>)
+                                         : reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_RNN, NT>);
+    cache[rnn_type] = asr_sweep_capacity(k, 512);
+  }
+  return cache[rnn_type];
+}
+
 extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, int ndir) {
   if (rnn_type < 0 || rnn_type > 2 || B <= 0 || T < 2) return 0;
   if (ndir != 1 && ndir != 2) return 0;
   int nt, G;
-  return sb_geometry(B, H, ndir, &nt, &G) ? 1 : 0;
+  if (!sb_geometry(B, H, ndir, &nt, &G)) return 0;
+  // all workgroups must be resident together: ask the device, keep a quarter of its capacity free (see rnn_sweep.hip)
+  const long wgs = (long)ndir * asr_cdiv(B, 16) * G * G;
+  const long cap = nt == 1 ? sb_capacity<1>(rnn_type) : sb_capacity<2>(rnn_type);
+  if (cap >= 0 && wgs * 4 > cap * 3) return 0;
+  return 1;
 }
 
 template <int NT>

@@ -97,7 +97,15 @@ class DeepSpeech2(ModelProto):
         self.F, self.C = frequency_dim, feature_dim
         fc, rest, bufs = self.param_shapes(frequency_dim, feature_dim)
         shapes = OrderedDict(list(fc.items()) + list(rest.items()))
-        self.store = ParamStore(shapes, [list(fc), list(rest)], self.device)
+        # all-reduce buckets in the order the backward pass completes them: Dense(V), then one bucket per recurrent layer
+        # from the top down (layer i's bucket travels while layer i-1 is swept), the convolutions with the bottom layer
+        per_layer = []
+        for i in range(self.Lr - 1, -1, -1):
+            names = [n for n in rest if n.startswith((f"recurrent/rnn_layers/{i}/", f"recurrent/batch_norm/{i}/"))]
+            if i == 0:
+                names += [n for n in rest if n.startswith("convolution/")]
+            per_layer.append(names)
+        self.store = ParamStore(shapes, [list(fc)] + per_layer, self.device)
         gen = torch.Generator().manual_seed(self.init_seed if self.init_seed is not None else random.randrange(2 ** 31))
         self.store.load({n: init_value(n, s, gen, self.rt) for n, s in shapes.items()})
         self.buffers = {n: init_value(n, s, gen).to(self.device) for n, s in bufs.items()}
@@ -224,7 +232,11 @@ class DeepSpeech2(ModelProto):
         ops.ctc_loss(ws.logits, labels, ws.B, ws.T2, self.blank_index, self.pad_index, ws.ctc_ws, ws.per_sample, ws.stats, True, grad_scale)
 
     def backward_segments(self, ws, audio):
-        return [lambda: self.backward_head(ws), lambda: self.backward_body(ws, audio)]
+        """One callable per gradient bucket, in completion order: Dense(V), recurrent layers from the top down (+ convolutions)."""
+        segs = [lambda: self.backward_head(ws)]
+        for i in range(self.Lr - 1, -1, -1):
+            segs.append(lambda i=i: self.backward_layer(ws, audio, i))
+        return segs
 
     def backward_ws(self, ws, audio):
         for seg in self.backward_segments(ws, audio):
@@ -236,32 +248,37 @@ class DeepSpeech2(ModelProto):
         dense_bwd(ws.xm, p["fully_connected/kernel"], ws.logits, g["fully_connected/kernel"], g["fully_connected/bias"], ws.dxm)
         ops.mask_rows(ws.dxm, ws.mask.view(-1), ws.dxm)
 
-    def backward_body(self, ws, audio):
+    def backward_layer(self, ws, audio, i):
+        """Recurrent layer i backwards (deepspeech2.py:109-119): BatchNorm, BiRNN; the convolutions follow layer 0."""
         p, g = self.store.p, self.store.g
         B, T2, H = ws.B, ws.T2, self.H
-        da = ws.dxm
-        dfin = [None, None]
-        if self.rt == "lstm":
-            ops.fill(ws.dc[0], 0.0)
-            ops.fill(ws.dc[1], 0.0)
-        for i in range(self.Lr - 1, -1, -1):
-            l, lw = self.layers[i], ws.layers[i]
-            bn = f"recurrent/batch_norm/{i}/"
-            y2 = lw["rnn"]["y"].view(B * T2, 2 * H)
-            ops.bn_bwd(y2, None, da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dy.view(B * T2, 2 * H), g[bn + "gamma"], g[bn + "beta"],
-                       ws.bn_ws, relu=False)
-            dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * H)
-            dfin = l.backward(lw["rnn"], ws.dy, dfin, ws.dc, dx, side=self._side)   # weight gradients beside the next layer's sweep
-            da = dx.view(B * T2, -1)
+        top = i == self.Lr - 1
+        if top:
+            ws.dfin_next = [None, None]
+            if self.rt == "lstm":
+                ops.fill(ws.dc[0], 0.0)
+                ops.fill(ws.dc[1], 0.0)
+        da = ws.dxm if top else ws.dx[(i + 1) & 1].view(B * T2, -1)
+        l, lw = self.layers[i], ws.layers[i]
+        bn = f"recurrent/batch_norm/{i}/"
+        y2 = lw["rnn"]["y"].view(B * T2, 2 * H)
+        ops.bn_bwd(y2, None, da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dy.view(B * T2, 2 * H), g[bn + "gamma"], g[bn + "beta"],
+                   ws.bn_ws, relu=False)
+        dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * H)
+        ws.dfin_next = l.backward(lw["rnn"], ws.dy, ws.dfin_next, ws.dc, dx, side=self._side)   # weight gradients beside the next layer's sweep
+        if getattr(self, "bucket_sync", False) and i > 0:
+            self._side.join()              # data parallel: this layer's gradients form a bucket, complete when the segment ends
+        if i > 0:
+            return
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
         dy = ws.dx0.view(ws.conv[-1].shape)
-        for i in range(len(ws.conv) - 1, -1, -1):
-            x = audio if i == 0 else ws.conv[i - 1]
-            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{i}/kernel"], self.strides[i])
-            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{i}/bias"])
-            if i > 0:
-                ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{i}/kernel"], ws.dconv[i - 1], self.strides[i])
-                dy = ws.dconv[i - 1]
+        for k in range(len(ws.conv) - 1, -1, -1):
+            x = audio if k == 0 else ws.conv[k - 1]
+            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
+            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
+            if k > 0:
+                ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
+                dy = ws.dconv[k - 1]
         self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API

@@ -171,8 +171,19 @@ class LAS(ModelProto):
         self.D0 = self.F2 * 32
         enc, dec, bufs = self.param_shapes(frequency_dim, feature_dim)
         shapes = OrderedDict(list(dec.items()) + list(enc.items()))
-        # all-reduce buckets in the order gradients become ready: decoder side first, then the encoder
-        self.store = ParamStore(shapes, [list(dec), list(enc)], self.device)
+        # all-reduce buckets in the order the backward pass completes them: the vocabulary layer (its gradient is ready
+        # before the decoder chain starts: 4.1 M of las_small's 16 M), the rest of the decoder side (embedding, cells, attention,
+        # state projections - complete after the chain, in flight during the encoder sweeps), then one bucket per encoder layer from
+        # the top down (layer i's bucket travels while layer i-1 is swept), the convolutions with the bottom layer
+        vocab = [n for n in dec if n.startswith("attend_and_speller/feedforward/")]
+        rest = [n for n in dec if n not in vocab]
+        per_layer = []
+        for i in range(self.Le - 1, -1, -1):
+            names = [n for n in enc if n.startswith((f"listener/encoder_layers/{i}/", f"listener/projection/{i}/", f"listener/batch_norm/{i}/"))]
+            if i == 0:
+                names += [n for n in enc if n.startswith("listener/conv")]
+            per_layer.append(names)
+        self.store = ParamStore(shapes, [vocab, rest] + per_layer, self.device)
         gen = torch.Generator().manual_seed(self.init_seed if self.init_seed is not None else random.randrange(2 ** 31))
         self.store.load({n: init_value(n, s, gen, self.rt) for n, s in shapes.items()})
         self.buffers = {n: init_value(n, s, gen).to(self.device) for n, s in bufs.items()}
@@ -482,26 +493,36 @@ class LAS(ModelProto):
             seg()
 
     def backward_segments(self, ws, audio):
-        """The backward pass as one callable per gradient bucket of the ParamStore, in the order the
-        buckets complete (decoder side, then encoder side): the data-parallel step all-reduces bucket
-        k while segment k+1 runs."""
-        return [lambda: self.backward_decoder(ws), lambda: self.backward_encoder(ws, audio)]
+        """The backward pass as one callable per gradient bucket of the ParamStore, in the order the buckets complete (vocabulary
+        layer, rest of the decoder side, encoder layers from the top down): the data-parallel step all-reduces bucket k while
+        segment k+1 runs."""
+        segs = [lambda: self.backward_vocab(ws), lambda: self.backward_decoder(ws)]
+        for i in range(self.Le - 1, -1, -1):
+            segs.append(lambda i=i: self.backward_encoder_layer(ws, audio, i))
+        return segs
+
+    def backward_vocab(self, ws):
+        """Vocabulary projection (las.py:291): its weight gradient and the gradient flowing into the decoder chain."""
+        assert ws.training, "backward needs a training-mode forward"
+        p, g = self.store.p, self.store.g
+        B, U, Hd = ws.B, ws.U, self.Hd
+        rate = self.dropout
+        mk, _ = self._drops(ws, 0, U, True)
+        y_last = ws.dec[-1]["y"].view(U * B, Hd)
+        src = ws.yd if rate > 0 else y_last
+        # (the weight gradient - 16 M outputs nobody downstream reads - may run beside the dX product on a side stream)
+        self._side_dec.run(lambda: dense_bwd(src, None, ws.logits, g["attend_and_speller/feedforward/kernel"], g["attend_and_speller/feedforward/bias"]))
+        dense_bwd(src, p["attend_and_speller/feedforward/kernel"], ws.logits, None, None, ws.dyd)
+        if rate > 0:
+            ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
+        self._side_dec.join()
 
     def backward_decoder(self, ws):
-        assert ws.training, "backward needs a training-mode forward"
         p, g = self.store.p, self.store.g
         B, U, T2, He, Hd, rt, V = ws.B, ws.U, ws.T2, self.He, self.Hd, self.rt, self.V
         rate = self.dropout
         mk, _ = self._drops(ws, 0, U, True)
         seed = self.seed if rate > 0 else None
-        # ---- vocabulary projection (las.py:291)
-        y_last = ws.dec[-1]["y"].view(U * B, Hd)
-        src = ws.yd if rate > 0 else y_last
-        # the vocabulary weight gradient (16 M outputs, nobody downstream reads it) runs beside the decoder chain
-        self._side_dec.run(lambda: dense_bwd(src, None, ws.logits, g["attend_and_speller/feedforward/kernel"], g["attend_and_speller/feedforward/bias"]))
-        dense_bwd(src, p["attend_and_speller/feedforward/kernel"], ws.logits, None, None, ws.dyd)
-        if rate > 0:
-            ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
         # ---- decoder steps in reverse (las.py:282-288).  Each cell hands ds (gradient wrt its gate sums,
         # written over its saved activations) to the cells that fed it; `ws.ddirect` carries the part of
         # dh that bypasses the gates (pad-token rows, GRU z*dh) along the single state chain.
@@ -607,26 +628,27 @@ class LAS(ModelProto):
                 ops.gemm(st_, dsrc, gW[d * He:(d + 1) * He], trans_a=True, accumulate=1)
                 dst = ws.dfin_h[d] if k == 0 else ws.dc_enc[d]
                 ops.gemm(dsrc, W[d * He:(d + 1) * He], dst, trans_b=True)
-        self._side_dec.join()
 
-    def backward_encoder(self, ws, audio):
+    def backward_encoder_layer(self, ws, audio, i):
+        """Encoder layer i backwards (las.py:190-193): BatchNorm+ReLU, projection, BiRNN; the convolutions follow layer 0."""
         p, g = self.store.p, self.store.g
         B, T2, He = ws.B, ws.T2, self.He
         rate = self.dropout
-        # ---- encoder layers in reverse (las.py:190-193)
-        da = ws.denc
-        dfin = list(ws.dfin_h)
-        for i in range(self.Le - 1, -1, -1):
-            l, lw = self.enc_layers[i], ws.layers[i]
-            bn = f"listener/batch_norm/{i}/"
-            ops.bn_bwd(lw["z"], lw["a"], da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dz, g[bn + "gamma"], g[bn + "beta"], ws.bn_ws, relu=True)
-            y2 = lw["rnn"]["y"].view(B * T2, 2 * He)
-            dense_bwd(y2, p[f"listener/projection/{i}/kernel"], ws.dz, g[f"listener/projection/{i}/kernel"],
-                      g[f"listener/projection/{i}/bias"], ws.dy.view(B * T2, 2 * He))
-            dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * He)
-            dh0 = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, side=self._side)   # weight gradients beside the next layer's sweep
-            dfin = dh0
-            da = dx.view(B * T2, -1)
+        top = i == self.Le - 1
+        da = ws.denc if top else (ws.dx[(i + 1) & 1]).view(B * T2, -1)
+        dfin = list(ws.dfin_h) if top else ws.dfin_next
+        l, lw = self.enc_layers[i], ws.layers[i]
+        bn = f"listener/batch_norm/{i}/"
+        ops.bn_bwd(lw["z"], lw["a"], da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dz, g[bn + "gamma"], g[bn + "beta"], ws.bn_ws, relu=True)
+        y2 = lw["rnn"]["y"].view(B * T2, 2 * He)
+        dense_bwd(y2, p[f"listener/projection/{i}/kernel"], ws.dz, g[f"listener/projection/{i}/kernel"],
+                  g[f"listener/projection/{i}/bias"], ws.dy.view(B * T2, 2 * He))
+        dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * He)
+        ws.dfin_next = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, side=self._side)
+        if getattr(self, "bucket_sync", False) or i == 0:
+            self._side.join()              # data parallel: this layer's gradients form a bucket, complete when the segment ends
+        if i > 0:
+            return
         # ---- convolutions (las.py:183-184)
         if rate > 0:
             ops.dropout_flat(ws.dx0, self.seed, R.STREAM_CONV2_DROP, rate)
@@ -638,7 +660,6 @@ class LAS(ModelProto):
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
         ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"])
-        self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):

@@ -327,6 +327,18 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     return c
 
 
+def bf16_to_f32(src: torch.Tensor, dst: torch.Tensor):
+    """dst (float32) = src (bfloat16, same numel), on the current stream."""
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and dst.numel() == src.numel() and src.is_contiguous() and dst.is_contiguous()
+    check(lib().asr_bf16_to_f32(C.c_void_p(src.data_ptr()), _p(dst), src.numel(), _stream()))
+    return dst
+
+
+def debug_occupy(blocks: int, threads: int, microseconds: int):
+    """Diagnostic: keep `blocks` workgroups busy for `microseconds` on the current stream (asr_debug_occupy)."""
+    check(lib().asr_debug_occupy(int(blocks), int(threads), int(microseconds), _stream()))
+
+
 # ----------------------------------------------------------------------------------------- recurrent layers
 def rnn_geometry(rnn_type: str, H: int, Ks: Sequence[int]) -> _lib.RnnGeom:
     g = _lib.RnnGeom()

@@ -27,12 +27,37 @@ class GradientExchange:
     On GPUs the reduction of bucket k is issued on a side stream as soon as backward segment k+1 has
     been enqueued, so RCCL traffic over xGMI overlaps the remaining backward kernels; on CPU tensors
     (gloo; used by the unit tests) it runs synchronously.  Replicas are expected to have scaled their
-    loss gradient by 1/world_size, so SUM yields the replica mean."""
+    loss gradient by 1/world_size, so SUM yields the replica mean.
+    wire_dtype=torch.bfloat16 (the las_large configuration): a bucket crosses the fabric as bf16 - converted on
+    the communication stream before and after the collective, half the bytes on the 153 GB/s xGMI links - and the sum of
+    the rounded replica gradients lands back in the f32 buffer (every rank ends with the same values)."""
 
-    def __init__(self, world_size: int, group=None, compute_stream=None):
+    def __init__(self, world_size: int, group=None, compute_stream=None, wire_dtype=torch.float32):
         self.world, self.group, self.stream = world_size, group, compute_stream
         self.comm_stream = torch.cuda.Stream() if (compute_stream is not None and world_size > 1) else None
+        self.wire_dtype = wire_dtype
+        self._wire = {}                                   # bucket address -> bf16 staging buffer
         self._pending = []
+
+    def _staging(self, bucket):
+        key = (bucket.data_ptr(), bucket.numel())
+        if key not in self._wire:
+            self._wire[key] = torch.empty(bucket.numel(), dtype=torch.bfloat16, device=bucket.device)
+        return self._wire[key]
+
+    def _all_reduce(self, bucket, dist):
+        if self.wire_dtype != torch.bfloat16:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        wire = self._staging(bucket)
+        if bucket.is_cuda:
+            ops.f32_to_bf16(bucket, wire)
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+            ops.bf16_to_f32(wire, bucket)
+        else:                                             # the gloo unit test only: no product path runs on CPU tensors
+            wire.copy_(bucket)
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+            bucket.copy_(wire)
 
     def reduce_async(self, bucket: torch.Tensor):
         """Start summing `bucket` (a contiguous 1-D view) across ranks."""
@@ -40,13 +65,13 @@ class GradientExchange:
             return
         import torch.distributed as dist
         if self.comm_stream is None:                      # CPU / gloo path
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(bucket, dist)
             return
         ready = torch.cuda.Event()
         ready.record(self.stream)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ready)
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(bucket, dist)
             done = torch.cuda.Event()
             done.record(self.comm_stream)
         self._pending.append(done)
@@ -101,7 +126,10 @@ class TrainStep:
         self._shapes: Dict[tuple, dict] = {}
         self.max_shapes = 16                       # input shapes kept alive (workspace + captured graphs each), least recently used evicted
         self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
-        self.exchange = GradientExchange(self.world, self.group, self.stream)
+        # --mixed-precision (BASELINE configs[4], las_large): gradients cross the fabric as bf16
+        wire = torch.bfloat16 if (ops.mixed_precision() and self.world > 1) else torch.float32
+        self.exchange = GradientExchange(self.world, self.group, self.stream, wire_dtype=wire)
+        model.bucket_sync = self.world > 1           # per-bucket completion of side-stream work only when buckets are exchanged
         self.iterations = 0
         self._replicas_synced = False
         if getattr(model, "built", False):
@@ -167,9 +195,14 @@ class TrainStep:
 
     def _segments(self, c, teacher):
         """The step as a list of stream-ordered callables; gradient bucket k is complete after
-        segment k+1 (segment 0 = front end + forward + loss)."""
+        segment k+1 (segment 0 = front end + forward + loss).  A single replica exchanges nothing: its whole backward
+        pass is one segment (one captured graph instead of one per bucket)."""
         segs = [lambda: self._fwd_loss(c, teacher)]
-        segs += self.model.backward_segments(c["ws"], c["feats"])
+        bsegs = self.model.backward_segments(c["ws"], c["feats"])
+        if self.world > 1:
+            segs += bsegs
+        else:
+            segs.append(lambda: [fn() for fn in bsegs])
         return segs
 
     def _run_segment(self, c, teacher, k, fn):
@@ -207,11 +240,11 @@ class TrainStep:
             c["tokens"].copy_(tokens, non_blocking=True)
             m.set_targets(c["ws"], c["tokens"], c["labels"])   # layout copies of the token rows (not captured)
             segs = self._segments(c, teacher)
-            buckets = m.store.bucket_views()
-            assert len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
+            buckets = m.store.bucket_views() if self.world > 1 else []
+            assert self.world == 1 or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
             for k, fn in enumerate(segs):
                 self._run_segment(c, teacher, k, fn)
-                if k >= 1:
+                if k >= 1 and buckets:
                     self.exchange.reduce_async(buckets[k - 1])
             self.exchange.wait()
             self._run_segment(c, teacher, "update", self._update)

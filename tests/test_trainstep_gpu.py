@@ -55,3 +55,87 @@ def test_mixed_precision_tracks_f32():
     scale = float(a.abs().max())
     diff = float((a - b).abs().max())
     assert 0.0 < diff < 3e-2 * scale, (diff, scale)
+
+
+def _las_trainer(He=32, seed=3, use_graph=True):
+    from speech_recognition_amd.models import LAS
+    from speech_recognition_amd.training import TrainStep
+    from speech_recognition_amd.utils import LRScheduler
+    model = LAS("lstm", 41, He, He, 2, 1, 0.1, 0.99, seed=seed).build(20, 3)
+    return TrainStep(model, LRScheduler(100, 1e-3, 1e-5), frontend=None, use_graph=use_graph), model
+
+
+def _las_batch(B=18, T=62, L=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, T, 20, 3, generator=g).cuda(), torch.full((B,), T, dtype=torch.int32).cuda(),
+            torch.randint(1, 41, (B, L), generator=g, dtype=torch.int32).cuda())
+
+
+def test_sweep_timeout_skips_the_update_and_surfaces_later():
+    """a hand-off time-out of a one-launch sweep must never be silent and never train on garbage.  With the
+    spin limit forced to 0 every sweep gives up: the affected steps leave parameters, Adam moments and the step counter
+    untouched (the flag rides in the last gradient bucket and gates adam_step / advance_state), the error is still on record
+    after later GOOD steps (update_freq > 1: nobody read the statistics in between), and reading them raises once and clears
+    it.  The limit is a launch argument (frozen into a captured graph), so the first part runs eagerly and the second part
+    captures its graphs while the limit is 0: the gating also holds inside graph replays."""
+    from speech_recognition_amd import ops
+    tr, model = _las_trainer(use_graph=False)
+    batch = _las_batch()
+    for _ in range(2):
+        ws = tr.step(*batch, use_teacher_forcing=True)
+    assert all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers)
+    tr.read_stats(ws)
+    before = model.store.flat.clone()
+    m_before, it_before = model.store.adam_m.clone(), int(model.state[0])
+    ops.rnn_sweep_set_spin_limit(0)
+    try:
+        for _ in range(2):
+            ws = tr.step(*batch, use_teacher_forcing=True)
+        tr.synchronize()
+    finally:
+        ops.rnn_sweep_set_spin_limit(1 << 18)
+    assert torch.equal(model.store.flat, before) and torch.equal(model.store.adam_m, m_before), "an invalid step must not update anything"
+    assert int(model.state[0]) == it_before and int(model.state[2]) == 1
+    ws = tr.step(*batch, use_teacher_forcing=True)       # a good step: trains again, the error stays on record
+    tr.synchronize()
+    assert int(model.state[0]) == it_before + 1 and not torch.equal(model.store.flat, before)
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        tr.read_stats(ws)
+    assert np.isfinite(tr.read_stats(ws)[0])             # raised once, cleared
+
+    tr2, model2 = _las_trainer(use_graph=True, seed=9)
+    init = model2.store.flat.clone()
+    ops.rnn_sweep_set_spin_limit(0)
+    try:
+        for _ in range(4):                               # eager, capture, replay, replay - all with the limit 0 baked in
+            ws2 = tr2.step(*batch, use_teacher_forcing=True)
+        tr2.synchronize()
+    finally:
+        ops.rnn_sweep_set_spin_limit(1 << 18)
+    assert torch.equal(model2.store.flat, init) and int(model2.state[0]) == 0 and int(model2.state[2]) == 1
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        tr2.read_stats(ws2)
+
+
+def test_sweeps_survive_foreign_kernels_holding_compute_units():
+    """while a side stream keeps most of the chip's compute units busy (a stand-in for RCCL channels next to the
+    backward sweeps under data parallelism), the one-launch sweeps - whose workgroups wait for each other - must neither time
+    out nor change their results: several of their workgroups share a CU."""
+    from speech_recognition_amd import ops
+    tr, model = _las_trainer(He=64, seed=5, use_graph=False)
+    tr2, model2 = _las_trainer(He=64, seed=5, use_graph=False)
+    batch = _las_batch(B=32, T=126, L=6, seed=2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.debug_occupy(192, 1024, 400000)              # 192 workgroups x 16 waves hold 192 of the 256 CUs for 0.4 s
+    losses = []
+    for _ in range(2):
+        ws = tr.step(*batch, use_teacher_forcing=True)
+        losses.append(tr.read_stats(ws)[0])              # raises on a hand-off time-out
+    side.synchronize()
+    for i in range(2):
+        ws2 = tr2.step(*batch, use_teacher_forcing=True)
+        assert abs(tr2.read_stats(ws2)[0] - losses[i]) <= 1e-5 * abs(losses[i])
+    assert all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers)
+    a, b = model.store.flat, model2.store.flat
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
