@@ -371,6 +371,35 @@ int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws
 void asr_rnn_sweep_set_spin_limit(int polls);
 int asr_rnn_sweep_spin_limit(void);
 
+/* ------------------------------------------------------------------------------------------
+ * One-launch forward sweep of the LAS decoder under teacher forcing (las.py:267-292 looped by las.py:368-377): all U steps of
+ * {attention, decoder LSTM 0, decoder LSTM 1} in one kernel (decoder_sweep.hip) - replaces U x {asr_attn_step_fwd,
+ * asr_rnn_cell_fwd x 2}.  256 resident workgroups keep the attention operands (Kq, enc: one (batch row, 1/8 of the frames)
+ * slice each, in LDS) and the packed cell weights (registers) on chip; a step is four sentinel hand-offs (see rnn_sweep.hip).
+ * Step-major tensors as in the per-step path: pre0 [U,B,4Hd] (embedding half of layer 0's input projection incl. bias),
+ * tokmask [U,B]; outputs p [U,B,T2], ctx [U,B,D], hin/cin [U+1,B,Hd] (row i+1 = last layer's state after step i; row 0 in),
+ * per layer y [U,B,Hd], saved gate activations [U,B,4Hd], and layer 0's state h0/c0 [U,B,Hd].  Dropout as in the per-step
+ * kernels: layer j's input dropout uses stream drop_stream0 + drop_stream_step * i + 2 + j.
+ * Supported (asr_decoder_sweep_supported): LSTM, 2 layers, B <= 32, Hd % 16 == 0 <= 256, D % 32 == 0 <= 512, T2 <= 256, a
+ * device with >= 256 compute units.  ws: asr_decoder_sweep_ws_floats() floats; error word / err_flag as for asr_rnn_sweep_fwd.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct asr_decoder_sweep {
+  int B, U, T2, Hd, D;
+  const float* Kq; const float* enc; const float* s0; const uint8_t* mask;   /* [B,T2,Hd], [B,T2,D], [B,T2] or NULL, [B,T2] */
+  const float* h_init; const float* c_init;                                   /* [B,Hd] contiguous                           */
+  const float* Wp0; int KSt0, ks0_ctx, ks0_h;     /* asr_rnn_pack image of layer 0: segments {context rows of the kernel, recurrent kernel} */
+  const float* Wp1; int KSt1, ks1_x, ks1_h;       /* layer 1: segments {kernel, recurrent kernel}                                        */
+  const float* pre0; const float* bias1;
+  const uint8_t* tokmask;
+  const uint32_t* seed; float drop_rate; uint32_t drop_stream0, drop_stream_step;
+  float* p; float* ctx; float* hin; float* cin;
+  float* y0; float* saved0; float* h0; float* c0;
+  float* y1; float* saved1;
+} asr_decoder_sweep;
+int asr_decoder_sweep_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D);
+long asr_decoder_sweep_ws_floats(int Hd, int D);
+int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, float* err_flag, void* stream);
+
 /* The same two steps with the two streamed operands given as bf16 images (asr_f32_to_bf16 of Kq and enc, made once per
  * training step): --mixed-precision.  The streams are what these kernels move, so the images halve their time; every
  * product and sum stays f32.  Needs Hd % 8 == 0, D % 8 == 0, 16-byte aligned h / dctx rows. */

@@ -30,6 +30,10 @@ from ..params import ParamStore, init_value
 from .model_proto import ModelProto
 
 
+# ASR_DECODER_SWEEP=0 forces one launch per decoder kernel and step (debugging / A-B timing)
+DECODER_SWEEP = os.environ.get("ASR_DECODER_SWEEP", "1") != "0"
+
+
 def get_rnn_cls(rnn_type: str) -> str:
     """las.py:10-17: validates the type (the 'class' here is just the kernel family name)."""
     if rnn_type in ("rnn", "lstm", "gru"):
@@ -425,6 +429,37 @@ class LAS(ModelProto):
                 st.saved, st.saved_ld = sv.data_ptr(), sv.stride(0)
             ops.rnn_cell_fwd(rt, B, Hd, [st], self.seed if rate > 0 else None)
 
+    def _decoder_sweep_ok(self, ws):
+        ok = getattr(ws, "_sweep_ok", None)
+        if ok is None:
+            ok = ws._sweep_ok = (ws.attn_fused is None and ops.decoder_sweep_supported(self.rt, self.Ld, ws.B, ws.U, ws.T2, self.Hd, 2 * self.He)
+                                 and torch.cuda.get_device_properties(ws.enc.device).multi_processor_count >= 256)
+        return ok
+
+    def _decoder_sweep(self, ws, training):
+        """Every AttendAndSpeller step of a teacher-forced pass (las.py:368-377) in ONE launch (decoder_sweep.hip): same operands
+        and the same saved tensors as U x _decoder_step."""
+        p, B, U, Hd, He = self.store.p, ws.B, ws.U, self.Hd, self.He
+        if getattr(ws, "dsweep_ws", None) is None:
+            ws.dsweep_ws = ops.decoder_sweep_ws(Hd, 2 * He, ws.enc.device)
+        rate = self.dropout if training else 0.0
+        d = _lib.DecoderSweep()
+        d.B, d.U, d.T2, d.Hd, d.D = B, U, ws.T2, Hd, 2 * He
+        d.Kq, d.enc, d.s0, d.mask = ws.Kq.data_ptr(), ws.enc.data_ptr(), ws.s0.data_ptr(), ws.mask.data_ptr()
+        d.h_init, d.c_init = ws.hin[0].data_ptr(), ws.cin[0].data_ptr()
+        c0, c1 = self.dec_cells
+        d.Wp0, d.KSt0, d.ks0_ctx, d.ks0_h = c0.Wp.data_ptr(), c0.geom.KSt, c0.geom.ks0[0], c0.geom.ks0[1]
+        d.Wp1, d.KSt1, d.ks1_x, d.ks1_h = c1.Wp.data_ptr(), c1.geom.KSt, c1.geom.ks0[0], c1.geom.ks0[1]
+        d.pre0 = ws.pre0.data_ptr()
+        d.bias1 = p["attend_and_speller/decoder_layers/1/cell/bias"].data_ptr()
+        d.tokmask = ws.tokmask.data_ptr()
+        d.seed = self.seed.data_ptr() if rate > 0 else None
+        d.drop_rate, d.drop_stream0, d.drop_stream_step = rate, R.STREAM_DEC, R.DEC_STREAMS_PER_STEP
+        d.p, d.ctx, d.hin, d.cin = ws.p.data_ptr(), ws.ctx.data_ptr(), ws.hin.data_ptr(), ws.cin.data_ptr()
+        d.y0, d.saved0, d.h0, d.c0 = ws.dec[0]["y"].data_ptr(), ws.dec[0]["saved"].data_ptr(), ws.dec[0]["h"].data_ptr(), ws.dec[0]["c"].data_ptr()
+        d.y1, d.saved1 = ws.dec[1]["y"].data_ptr(), ws.dec[1]["saved"].data_ptr()
+        ops.decoder_sweep_fwd(d, ws.dsweep_ws, getattr(self.store, "err_flag", None))
+
     # ------------------------------------------------------------------------------------------ forward
     def draw_teacher_forcing(self) -> bool:
         """las.py:366: one coin per batch, also at eval."""
@@ -452,8 +487,11 @@ class LAS(ModelProto):
         ws.training, ws.teacher = training, use_teacher_forcing
         if use_teacher_forcing:
             self._embed(ws, 0, U, training)
-            for i in range(U):
-                self._decoder_step(ws, i, training)
+            if DECODER_SWEEP and self._decoder_sweep_ok(ws):
+                self._decoder_sweep(ws, training)                     # all U steps in one launch
+            else:
+                for i in range(U):
+                    self._decoder_step(ws, i, training)
             self._vocab(ws, 0, U, training)
         else:
             for i in range(U):

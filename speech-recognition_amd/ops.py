@@ -492,6 +492,27 @@ def back_src(D, W, rnn_type, H, kind, drop=None):
     return s
 
 
+# ----------------------------------------------------------------------------------------- decoder sweep
+def decoder_sweep_supported(rnn_type, num_layers, B, U, T2, Hd, D) -> bool:
+    if rnn_type != "lstm":
+        return False
+    return bool(lib().asr_decoder_sweep_supported(rnn_type_id(rnn_type), num_layers, B, U, T2, Hd, D))
+
+
+def decoder_sweep_ws(Hd, D, device="cuda"):
+    return torch.zeros(int(lib().asr_decoder_sweep_ws_floats(Hd, D)), device=device, dtype=torch.float32)
+
+
+def decoder_sweep_error(ws) -> int:
+    """Non-zero if a hand-off of the last decoder sweep timed out (synchronises): (stage code | step << 8)."""
+    return int(ws[-288:-287].view(torch.int32)[0].item())
+
+
+def decoder_sweep_fwd(desc: "_lib.DecoderSweep", ws, err_flag=None):
+    """All decoder steps of a teacher-forced LAS forward pass in one launch (asr_decoder_sweep_fwd)."""
+    check(lib().asr_decoder_sweep_fwd(C.byref(desc), _p(ws), _p(err_flag), _stream()))
+
+
 # ----------------------------------------------------------------------------------------- cells (decoder steps)
 def rnn_cell_fwd(rnn_type, B, H, steps, seed=None):
     """steps: list (1 or 2 directions) of _lib.RnnStepFwd."""

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a test that stops making progress must fail with a traceback, not hang the suite: every wait on the device is bounded
+    # (the one-launch sweeps give up after ~0.3 s), so ten minutes of silence is a defect worth a stack dump
+    if config.pluginmanager.hasplugin("timeout") and not config.getoption("timeout", None):
+        config.option.timeout = 900
+    if getattr(config.option, "faulthandler_timeout", None) in (None, 0.0):
+        try:
+            config._inicache["faulthandler_timeout"] = 600.0
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")

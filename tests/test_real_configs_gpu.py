@@ -176,6 +176,7 @@ def test_las_small_yml_training_step_at_full_geometry(B):
     assert abs(st[0] - float(loss_r.detach())) < 1e-3, (st[0], float(loss_r))
     assert st[2] == count_r and abs(st[1] - correct_r) <= 1          # an arg-max tie may flip one of the 243 positions
     assert all(f and b for f, b in _persistent_layers(ws)), "the encoder layers must run the persistent kernels the benchmark times"
+    assert getattr(ws, "_sweep_ok", False), "the decoder steps must run as the one-launch decoder sweep the benchmark times"
     worst = _check_grads(model, leaves, 5e-3, LAS_NAMED)
     print(f"las_small B={B}: loss {st[0]:.5f} (oracle {float(loss_r):.5f}), worst gradient {worst}")
 
@@ -357,9 +358,46 @@ def test_las_whole_model_gradients_through_persistent_kernels(rt):
     torch.cuda.synchronize()
     assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
     assert _persistent_layers(ws) == [(True, True)] * 2
+    assert getattr(ws, "_sweep_ok", False) == (rt == "lstm"), "LSTM decoders run the one-launch decoder sweep"
     _check_grads(m, leaves, 2e-3)
     for n, v in m.buffers.items():
         assert_close(v, aux["bn_updates"][n], 1e-4, n)
+
+
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (32, 200, 9, 64, 48, 0.0), (5, 40, 3, 16, 16, 0.2), (32, 999, 12, 256, 256, 0.15)])
+def test_decoder_sweep_equals_per_step_kernels(B, T, U, He, Hd, dropout):
+    """The one-launch decoder sweep (all U steps of attention + two LSTM cells, decoder_sweep.hip) against the per-step kernels it
+    replaces, on the same model and batch: probabilities, contexts, gate activations, states and logits - equal to f32 rounding
+    (1e-5 of the largest entry; the chunked softmax and the MFMA summation order differ), same dropout masks."""
+    from speech_recognition_amd.models import LAS
+    from speech_recognition_amd.models import las as las_mod
+    V = 97
+    g = torch.Generator().manual_seed(B + T + U)
+    audio = torch.randn(B, T, 20, 3, generator=g)
+    audio[1, T // 2:] = 0.0
+    audio[B - 1, 3 * T // 4:] = 0.0
+    tokens = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32)
+    tokens[1, U // 2:] = 0
+    outs = {}
+    for sweep in (True, False):
+        las_mod.DECODER_SWEEP = sweep
+        try:
+            m = LAS("lstm", V, He, Hd, 1, 2, dropout, 0.99, 0, seed=3).build(20, 3)
+            m.state[1] = 77
+            ws = m._workspace(B, T, U)
+            ws.toks_T[:U].copy_(tokens.t().cuda())
+            m.forward_ws(ws, audio.cuda(), True, True)
+            torch.cuda.synchronize()
+            assert getattr(ws, "_sweep_ok", False) == sweep
+            if sweep:
+                from speech_recognition_amd import ops
+                assert not ops.decoder_sweep_error(ws.dsweep_ws), "decoder sweep: a hand-off timed out"
+            outs[sweep] = dict(p=ws.p.clone(), ctx=ws.ctx.clone(), hin=ws.hin.clone(), cin=ws.cin.clone(), logits=ws.logits.clone(),
+                               **{f"{k}{j}": ws.dec[j][k].clone() for j in range(2) for k in ws.dec[j]})
+        finally:
+            las_mod.DECODER_SWEEP = True
+    for k, ref in outs[False].items():
+        assert_close(outs[True][k], ref, 1e-5, k)
 
 
 @pytest.mark.parametrize("rt", ["gru", "rnn"])
