@@ -400,6 +400,32 @@ int asr_decoder_sweep_supported(int rnn_type, int num_layers, int B, int U, int 
 long asr_decoder_sweep_ws_floats(int Hd, int D);
 int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, float* err_flag, void* stream);
 
+/* The mirror for the backward pass (the decoder loop of las.py:368-377 differentiated; replaces U x {two cell-backward launches,
+ * the context-gradient launch, the attention-backward launches} of asr_rnn_cell_bwd / asr_attn_step_bwd): from the forward
+ * sweep's saved tensors and dy1 = gradient wrt the last layer's outputs [U*B, Hd] it writes
+ *   ds0 / ds1 [U,B,4Hd]  gradients wrt the gate sums of the two layers (OUT OF PLACE: must not alias saved0 / saved1),
+ *   de [U,B,T2]          gradient wrt the attention scores,   dctx [U,B,D]  gradient wrt the context (after layer 0's input dropout),
+ *   dh_init / dc_init [B,Hd]  gradients wrt the decoder's initial state.
+ * U1/W1/U0/W0: recurrent_kernel and kernel of layers 1 and 0, row-major [rows, 4Hd] (W0 has Hd embedding rows, then D context rows).
+ * Pad-token rows (tokmask 0) carry the state gradients through unchanged.  Supported (asr_decoder_sweep_bwd_supported): LSTM,
+ * 2 layers, B <= 32, Hd in {16..128 step 16, 160..256 step 32}, D/4 a power of two <= 128 with D % (16 G) == 0 and D/G <= 64
+ * (G = Hd/16 or Hd/32), T2 <= 256, >= 256 compute units.  ws: asr_decoder_sweep_bwd_ws_floats() floats; error words as forward. */
+typedef struct asr_decoder_sweep_grad {
+  int B, U, T2, Hd, D;
+  const float* Kq; const float* enc;                 /* [B,T2,Hd], [B,T2,D]                               */
+  const float* p; const float* ctx;                  /* forward outputs [U,B,T2], [U,B,D]                 */
+  const float* saved0; const float* saved1;          /* gate activations [U,B,4Hd]                        */
+  const float* cin; const float* c0;                 /* [U+1,B,Hd] (row i = last layer's c before step i), [U,B,Hd] */
+  const uint8_t* tokmask;                            /* [U,B]                                             */
+  const float* dy1; long dy1_ld;
+  const float* U1; const float* W1; const float* U0; const float* W0;
+  const uint32_t* seed; float drop_rate; uint32_t drop_stream0, drop_stream_step;
+  float* ds0; float* ds1; float* de; float* dctx; float* dh_init; float* dc_init;
+} asr_decoder_sweep_grad;
+int asr_decoder_sweep_bwd_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D);
+long asr_decoder_sweep_bwd_ws_floats(int Hd, int D);
+int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws, float* err_flag, void* stream);
+
 /* The same two steps with the two streamed operands given as bf16 images (asr_f32_to_bf16 of Kq and enc, made once per
  * training step): --mixed-precision.  The streams are what these kernels move, so the images halve their time; every
  * product and sum stays f32.  Needs Hd % 8 == 0, D % 8 == 0, 16-byte aligned h / dctx rows. */

@@ -86,6 +86,15 @@ class DecoderSweep(C.Structure):
                 ("y0", c_f32p), ("saved0", c_f32p), ("h0", c_f32p), ("c0", c_f32p), ("y1", c_f32p), ("saved1", c_f32p)]
 
 
+class DecoderSweepGrad(C.Structure):
+    _fields_ = [("B", C.c_int), ("U", C.c_int), ("T2", C.c_int), ("Hd", C.c_int), ("D", C.c_int),
+                ("Kq", c_f32p), ("enc", c_f32p), ("p", c_f32p), ("ctx", c_f32p), ("saved0", c_f32p), ("saved1", c_f32p),
+                ("cin", c_f32p), ("c0", c_f32p), ("tokmask", c_f32p), ("dy1", c_f32p), ("dy1_ld", c_long),
+                ("U1", c_f32p), ("W1", c_f32p), ("U0", c_f32p), ("W0", c_f32p),
+                ("seed", c_f32p), ("drop_rate", C.c_float), ("drop_stream0", C.c_uint32), ("drop_stream_step", C.c_uint32),
+                ("ds0", c_f32p), ("ds1", c_f32p), ("de", c_f32p), ("dctx", c_f32p), ("dh_init", c_f32p), ("dc_init", c_f32p)]
+
+
 class RnnSeqGrad(C.Structure):
     _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
                 ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("direct", c_f32p * 2), ("dh0", c_f32p * 2),
@@ -115,7 +124,7 @@ AUDIO_FORMATS = {"wav": 0, "flac": 1, "pcm": 2}
 
 STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom, "asr_audio_info_t": AudioInfo,
            "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_back_src": RnnBackSrc, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
-           "asr_rnn_seq_grad": RnnSeqGrad, "asr_decoder_sweep": DecoderSweep, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
+           "asr_rnn_seq_grad": RnnSeqGrad, "asr_decoder_sweep": DecoderSweep, "asr_decoder_sweep_grad": DecoderSweepGrad, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
            "asr_lr_schedule": LrSchedule}
 
 # symbol -> (restype, argtypes); every function declared in include/asr_mi355x.h
@@ -153,6 +162,9 @@ SIGNATURES = {
     "asr_decoder_sweep_supported": (C.c_int, [C.c_int] * 7),
     "asr_decoder_sweep_ws_floats": (c_long, [C.c_int, C.c_int]),
     "asr_decoder_sweep_fwd": (C.c_int, [C.POINTER(DecoderSweep), _P, _P, _P]),
+    "asr_decoder_sweep_bwd_supported": (C.c_int, [C.c_int] * 7),
+    "asr_decoder_sweep_bwd_ws_floats": (c_long, [C.c_int, C.c_int]),
+    "asr_decoder_sweep_bwd": (C.c_int, [C.POINTER(DecoderSweepGrad), _P, _P, _P]),
     "asr_conv2d_out_dims": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "asr_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_uint32, C.c_float, _P]),
     "asr_conv2d_bwd_filter": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),

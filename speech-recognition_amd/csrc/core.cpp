@@ -29,6 +29,7 @@ extern "C" long asr_struct_size(const char* name) {
   SZ(asr_rnn_seq);
   SZ(asr_rnn_seq_grad);
   SZ(asr_decoder_sweep);
+  SZ(asr_decoder_sweep_grad);
   SZ(asr_conv_desc);
   SZ(asr_rowdrop);
   SZ(asr_lr_schedule);

@@ -32,6 +32,7 @@ from .model_proto import ModelProto
 
 # ASR_DECODER_SWEEP=0 forces one launch per decoder kernel and step (debugging / A-B timing)
 DECODER_SWEEP = os.environ.get("ASR_DECODER_SWEEP", "1") != "0"
+DECODER_SWEEP_BWD = os.environ.get("ASR_DECODER_SWEEP_BWD", "1") != "0"     # the backward loop alone
 
 
 def get_rnn_cls(rnn_type: str) -> str:
@@ -460,6 +461,39 @@ class LAS(ModelProto):
         d.y1, d.saved1 = ws.dec[1]["y"].data_ptr(), ws.dec[1]["saved"].data_ptr()
         ops.decoder_sweep_fwd(d, ws.dsweep_ws, getattr(self.store, "err_flag", None))
 
+    def _decoder_sweep_bwd_ok(self, ws):
+        ok = getattr(ws, "_sweep_bwd_ok", None)
+        if ok is None:
+            ok = ws._sweep_bwd_ok = (DECODER_SWEEP and DECODER_SWEEP_BWD and ws.attn_fused is None and
+                                     ops.decoder_sweep_bwd_supported(self.rt, self.Ld, ws.B, ws.U, ws.T2, self.Hd, 2 * self.He)
+                                     and torch.cuda.get_device_properties(ws.enc.device).multi_processor_count >= 256)
+        return ok
+
+    def _decoder_sweep_bwd(self, ws):
+        """The decoder loop of backward_decoder (las.py:282-288 differentiated, U-1 .. 0) in ONE launch: gate-sum gradients of both
+        layers (out of place, ws.dec[j]["ds"]), score gradients ws.ds, context gradients ws.dctx, initial-state gradients
+        ws.dhs / ws.dc_dec - what U x {cell backward x 2, context gradient, attention backward} leave behind."""
+        p, B, U, Hd, He = self.store.p, ws.B, ws.U, self.Hd, self.He
+        if getattr(ws, "dsweep_bwd_ws", None) is None:
+            ws.dsweep_bwd_ws = ops.decoder_sweep_bwd_ws(Hd, 2 * He, ws.enc.device)
+            for j in range(self.Ld):
+                ws.dec[j]["ds"] = torch.empty_like(ws.dec[j]["saved"])
+        rate = self.dropout
+        dk = "attend_and_speller/decoder_layers/{}/cell/"
+        d = _lib.DecoderSweepGrad()
+        d.B, d.U, d.T2, d.Hd, d.D = B, U, ws.T2, Hd, 2 * He
+        d.Kq, d.enc, d.p, d.ctx = ws.Kq.data_ptr(), ws.enc.data_ptr(), ws.p.data_ptr(), ws.ctx.data_ptr()
+        d.saved0, d.saved1 = ws.dec[0]["saved"].data_ptr(), ws.dec[1]["saved"].data_ptr()
+        d.cin, d.c0, d.tokmask = ws.cin.data_ptr(), ws.dec[0]["c"].data_ptr(), ws.tokmask.data_ptr()
+        d.dy1, d.dy1_ld = ws.dyd.data_ptr(), ws.dyd.stride(0)
+        d.U1, d.W1 = p[dk.format(1) + "recurrent_kernel"].data_ptr(), p[dk.format(1) + "kernel"].data_ptr()
+        d.U0, d.W0 = p[dk.format(0) + "recurrent_kernel"].data_ptr(), p[dk.format(0) + "kernel"].data_ptr()
+        d.seed = self.seed.data_ptr() if rate > 0 else None
+        d.drop_rate, d.drop_stream0, d.drop_stream_step = rate, R.STREAM_DEC, R.DEC_STREAMS_PER_STEP
+        d.ds0, d.ds1 = ws.dec[0]["ds"].data_ptr(), ws.dec[1]["ds"].data_ptr()
+        d.de, d.dctx, d.dh_init, d.dc_init = ws.ds.data_ptr(), ws.dctx.data_ptr(), ws.dhs.data_ptr(), ws.dc_dec.data_ptr()
+        ops.decoder_sweep_bwd(d, ws.dsweep_bwd_ws, getattr(self.store, "err_flag", None))
+
     # ------------------------------------------------------------------------------------------ forward
     def draw_teacher_forcing(self) -> bool:
         """las.py:366: one coin per batch, also at eval."""
@@ -564,63 +598,67 @@ class LAS(ModelProto):
         # ---- decoder steps in reverse (las.py:282-288).  Each cell hands ds (gradient wrt its gate sums,
         # written over its saved activations) to the cells that fed it; `ws.ddirect` carries the part of
         # dh that bypasses the gates (pad-token rows, GRU z*dh) along the single state chain.
-        if rt == "lstm":
-            ops.fill(ws.dc_dec, 0.0)
-        ops.fill(ws.ddirect, 0.0)
-        last = self.Ld - 1
-        enc3, Kq3 = ws.enc.view(B, T2, 2 * He), ws.Kq.view(B, T2, Hd)
-        dk = "attend_and_speller/decoder_layers/{}/cell/"
-        W0 = p[dk.format(0) + "kernel"]
-        for i in range(U - 1, -1, -1):
-            base = R.STREAM_DEC + R.DEC_STREAMS_PER_STEP * i
-            for j in range(last, -1, -1):
-                h_in, c_in, h_out, c_out = self._cell_states(ws, j, i)
-                st = _lib.RnnStepBwd()
-                st.n_units = Hd
-                if j < last:      # state and output both feed layer j+1 of the same step
-                    dn = ws.dec[j + 1]["saved"][i]
-                    st.srcA = ops.back_src(dn, p[dk.format(j + 1) + "recurrent_kernel"], rt, Hd, "rec")
-                    st.srcB = ops.back_src(dn, p[dk.format(j + 1) + "kernel"], rt, Hd, "input", (rate, base + 2 + j + 1, Hd, 0))
-                else:             # last layer: state feeds layer 0 + attention of step i+1; output feeds Dense(V)
-                    if i < U - 1:
-                        st.srcA = ops.back_src(ws.dec[0]["saved"][i + 1], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
-                        st.addA, st.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
-                    dyl = ws.dyd[i * B:(i + 1) * B]
-                    st.addB, st.addB_ld = dyl.data_ptr(), dyl.stride(0)
-                st.direct, st.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
-                if rt == "lstm":
-                    st.dc, st.dc_ld = ws.dc_dec.data_ptr(), ws.dc_dec.stride(0)
-                    st.c_prev, st.c_prev_ld = c_in.data_ptr(), c_in.stride(0)
-                    st.c_out, st.c_out_ld = c_out.data_ptr(), c_out.stride(0)
-                st.mask, st.mask_ld = ws.tokmask[i].data_ptr(), 1
-                sv = ws.dec[j]["saved"][i]
-                st.saved, st.saved_ld = sv.data_ptr(), sv.stride(0)
-                st.dslots, st.dslots_ld = sv.data_ptr(), sv.stride(0)
-                st.h_prev, st.h_prev_ld = h_in.data_ptr(), h_in.stride(0)
-                ops.rnn_cell_bwd(rt, B, [st], seed)
-            # context gradient = layer 0's input gradient over the context rows of its kernel, through its input dropout
+        swept = self._decoder_sweep_bwd_ok(ws)
+        if swept:
+            self._decoder_sweep_bwd(ws)                               # all U steps in one launch (decoder_sweep_bwd.hip)
+        else:
+            if rt == "lstm":
+                ops.fill(ws.dc_dec, 0.0)
+            ops.fill(ws.ddirect, 0.0)
+            last = self.Ld - 1
+            enc3, Kq3 = ws.enc.view(B, T2, 2 * He), ws.Kq.view(B, T2, Hd)
+            dk = "attend_and_speller/decoder_layers/{}/cell/"
+            W0 = p[dk.format(0) + "kernel"]
+            for i in range(U - 1, -1, -1):
+                base = R.STREAM_DEC + R.DEC_STREAMS_PER_STEP * i
+                for j in range(last, -1, -1):
+                    h_in, c_in, h_out, c_out = self._cell_states(ws, j, i)
+                    st = _lib.RnnStepBwd()
+                    st.n_units = Hd
+                    if j < last:      # state and output both feed layer j+1 of the same step
+                        dn = ws.dec[j + 1]["saved"][i]
+                        st.srcA = ops.back_src(dn, p[dk.format(j + 1) + "recurrent_kernel"], rt, Hd, "rec")
+                        st.srcB = ops.back_src(dn, p[dk.format(j + 1) + "kernel"], rt, Hd, "input", (rate, base + 2 + j + 1, Hd, 0))
+                    else:             # last layer: state feeds layer 0 + attention of step i+1; output feeds Dense(V)
+                        if i < U - 1:
+                            st.srcA = ops.back_src(ws.dec[0]["saved"][i + 1], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
+                            st.addA, st.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
+                        dyl = ws.dyd[i * B:(i + 1) * B]
+                        st.addB, st.addB_ld = dyl.data_ptr(), dyl.stride(0)
+                    st.direct, st.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
+                    if rt == "lstm":
+                        st.dc, st.dc_ld = ws.dc_dec.data_ptr(), ws.dc_dec.stride(0)
+                        st.c_prev, st.c_prev_ld = c_in.data_ptr(), c_in.stride(0)
+                        st.c_out, st.c_out_ld = c_out.data_ptr(), c_out.stride(0)
+                    st.mask, st.mask_ld = ws.tokmask[i].data_ptr(), 1
+                    sv = ws.dec[j]["saved"][i]
+                    st.saved, st.saved_ld = sv.data_ptr(), sv.stride(0)
+                    st.dslots, st.dslots_ld = sv.data_ptr(), sv.stride(0)
+                    st.h_prev, st.h_prev_ld = h_in.data_ptr(), h_in.stride(0)
+                    ops.rnn_cell_bwd(rt, B, [st], seed)
+                # context gradient = layer 0's input gradient over the context rows of its kernel, through its input dropout
+                lin = _lib.RnnStepBwd()
+                lin.n_units = 2 * He
+                lin.srcB = ops.back_src(ws.dec[0]["saved"][i], W0[Hd:], rt, Hd, "input", (rate, base + 2, Hd + 2 * He, Hd))
+                lin.out, lin.out_ld = ws.dctx[i].data_ptr(), ws.dctx[i].stride(0)
+                ops.rnn_cell_bwd(rt, B, [lin], seed)
+                if ws.attn_fused is not None:
+                    ops.attn_fused_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.attn_fused, ws.ds[i], ws.dh_attn, accumulate=False)
+                else:
+                    ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False,
+                                      images=getattr(ws, "attn_images", None))
+            # gradient wrt the decoder's initial states (= listener state projections)
             lin = _lib.RnnStepBwd()
-            lin.n_units = 2 * He
-            lin.srcB = ops.back_src(ws.dec[0]["saved"][i], W0[Hd:], rt, Hd, "input", (rate, base + 2, Hd + 2 * He, Hd))
-            lin.out, lin.out_ld = ws.dctx[i].data_ptr(), ws.dctx[i].stride(0)
-            ops.rnn_cell_bwd(rt, B, [lin], seed)
-            if ws.attn_fused is not None:
-                ops.attn_fused_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.attn_fused, ws.ds[i], ws.dh_attn, accumulate=False)
-            else:
-                ops.attn_step_bwd(ws.dctx[i], ws.p[i], Kq3, enc3, ws.dp, ws.ds[i], ws.dh_attn, accumulate=False,
-                                  images=getattr(ws, "attn_images", None))
-        # gradient wrt the decoder's initial states (= listener state projections)
-        lin = _lib.RnnStepBwd()
-        lin.n_units = Hd
-        lin.srcA = ops.back_src(ws.dec[0]["saved"][0], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
-        lin.addA, lin.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
-        lin.direct, lin.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
-        lin.out, lin.out_ld = ws.dhs.data_ptr(), ws.dhs.stride(0)
-        ops.rnn_cell_bwd(rt, B, [lin], None)
+            lin.n_units = Hd
+            lin.srcA = ops.back_src(ws.dec[0]["saved"][0], p[dk.format(0) + "recurrent_kernel"], rt, Hd, "rec")
+            lin.addA, lin.addA_ld = ws.dh_attn.data_ptr(), ws.dh_attn.stride(0)
+            lin.direct, lin.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
+            lin.out, lin.out_ld = ws.dhs.data_ptr(), ws.dhs.stride(0)
+            ops.rnn_cell_bwd(rt, B, [lin], None)
         # ---- decoder weight gradients, batched over steps
         for j in range(self.Ld):
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"
-            ds2 = ws.dec[j]["saved"].view(U * B, -1)
+            ds2 = (ws.dec[j]["ds"] if swept else ws.dec[j]["saved"]).view(U * B, -1)
             gW, gU, gb = g[pre + "kernel"], g[pre + "recurrent_kernel"], g[pre + "bias"]
             if j == 0:
                 hprev = ws.hin[:U].view(U * B, Hd)

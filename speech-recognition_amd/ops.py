@@ -513,6 +513,21 @@ def decoder_sweep_fwd(desc: "_lib.DecoderSweep", ws, err_flag=None):
     check(lib().asr_decoder_sweep_fwd(C.byref(desc), _p(ws), _p(err_flag), _stream()))
 
 
+def decoder_sweep_bwd_supported(rnn_type, num_layers, B, U, T2, Hd, D) -> bool:
+    if rnn_type != "lstm":
+        return False
+    return bool(lib().asr_decoder_sweep_bwd_supported(rnn_type_id(rnn_type), num_layers, B, U, T2, Hd, D))
+
+
+def decoder_sweep_bwd_ws(Hd, D, device="cuda"):
+    return torch.zeros(int(lib().asr_decoder_sweep_bwd_ws_floats(Hd, D)), device=device, dtype=torch.float32)
+
+
+def decoder_sweep_bwd(desc: "_lib.DecoderSweepGrad", ws, err_flag=None):
+    """All decoder steps of the backward pass of a teacher-forced LAS step in one launch (asr_decoder_sweep_bwd)."""
+    check(lib().asr_decoder_sweep_bwd(C.byref(desc), _p(ws), _p(err_flag), _stream()))
+
+
 # ----------------------------------------------------------------------------------------- cells (decoder steps)
 def rnn_cell_fwd(rnn_type, B, H, steps, seed=None):
     """steps: list (1 or 2 directions) of _lib.RnnStepFwd."""

@@ -64,6 +64,10 @@ def _worker(rank, world, port, q):
             params.append(model.store.flat.cpu().numpy().copy())
             persistent.append(all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers))
         q.put((rank, own, params, grads, losses, persistent, model.state.cpu().numpy().copy()))   # by value (no fd passing)
+    except BaseException:                                        # surface the failure at once instead of letting the parent wait
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -76,7 +80,17 @@ def test_two_rank_training_equals_manual_replica_mean():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=240) for _ in procs), key=lambda x: x[0])
+    res = []
+    for _ in procs:
+        r = q.get(timeout=240)
+        if r[0] == "error":
+            for p in procs:
+                p.join(5)
+                if p.is_alive():
+                    p.kill()                                     # the exact processes this test started
+            pytest.fail(f"rank {r[1]} failed:\n{r[2]}")
+        res.append(r)
+    res.sort(key=lambda x: x[0])
     for p in procs:
         p.join(60)
     (_, own0, p0, g0, l0, pers0, st0), (_, own1, p1, g1, l1, pers1, st1) = res

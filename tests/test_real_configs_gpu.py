@@ -400,6 +400,49 @@ def test_decoder_sweep_equals_per_step_kernels(B, T, U, He, Hd, dropout):
         assert_close(outs[True][k], ref, 1e-5, k)
 
 
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (5, 40, 3, 16, 16, 0.2), (32, 120, 7, 64, 128, 0.0), (32, 999, 12, 256, 256, 0.15)])
+def test_decoder_sweep_bwd_equals_per_step_kernels(B, T, U, He, Hd, dropout):
+    """The one-launch BACKWARD decoder sweep (decoder_sweep_bwd.hip) against the per-step kernels it replaces (two cell-backward
+    launches, the context gradient and the attention backward per step), same model, batch and dropout masks: score / context /
+    gate-sum / initial-state gradients and every parameter gradient of the step - equal to f32 rounding (3e-5 of the largest entry:
+    the square decomposition sums the transposed products in a different order)."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.models import LAS
+    from speech_recognition_amd.models import las as las_mod
+    V = 97
+    g = torch.Generator().manual_seed(B + T + U)
+    audio = torch.randn(B, T, 20, 3, generator=g)
+    audio[1, T // 2:] = 0.0
+    audio[B - 1, 3 * T // 4:] = 0.0
+    tokens = torch.randint(1, V, (B, U + 1), generator=g, dtype=torch.int32)
+    tokens[1, U // 2:] = 0
+    tokens[B - 2, U - 1:] = 0
+    outs = {}
+    for sweep in (True, False):
+        las_mod.DECODER_SWEEP_BWD = sweep
+        try:
+            m = LAS("lstm", V, He, Hd, 1, 2, dropout, 0.99, 0, seed=3).build(20, 3)
+            m.state[1] = 77
+            ws, labels = m.train_workspace(B, T, U + 1)
+            m.set_targets(ws, tokens.cuda(), labels)
+            ops.fill(m.store.grad, 0.0)
+            ag = audio.cuda()
+            m.forward_ws(ws, ag, True, True)
+            m.loss_and_grad(ws, labels)
+            m.backward_ws(ws, ag)
+            torch.cuda.synchronize()
+            assert getattr(ws, "_sweep_bwd_ok", False) == sweep
+            if sweep:
+                assert not ops.decoder_sweep_error(ws.dsweep_bwd_ws), "backward decoder sweep: a hand-off timed out"
+            outs[sweep] = dict(de=ws.ds.clone(), dctx=ws.dctx.clone(), dhs=ws.dhs.clone(), dc=ws.dc_dec.clone(),
+                               ds0=(ws.dec[0]["ds"] if sweep else ws.dec[0]["saved"]).clone(),
+                               ds1=(ws.dec[1]["ds"] if sweep else ws.dec[1]["saved"]).clone(), grad=m.store.grad.clone())
+        finally:
+            las_mod.DECODER_SWEEP_BWD = True
+    for k, ref in outs[False].items():
+        assert_close(outs[True][k], ref, 3e-5, k)
+
+
 @pytest.mark.parametrize("rt", ["gru", "rnn"])
 def test_ds2_whole_model_gradients_through_persistent_kernels(rt):
     from speech_recognition_amd import ops
