@@ -31,11 +31,13 @@ PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
 WORKLOADS = {
-    # traffic: HBM-side bytes per step from the PMC passes of profiles/r01_las_small_pmc_hbm_traffic.txt
-    # (2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate, measured offline
+    # traffic: memory-side bytes per step from the PMC passes of profiles/r02_las_small_pmc_hbm_traffic.txt
+    # (2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate, measured offline; about 60 % of it
+    # is the inter-workgroup exchange of the one-launch sweeps (write-through stores, L1-bypassing polls), which the counters
+    # tally at the fabric although the Infinity Cache serves it
     # algorithmic_bytes: activations kept for backward written once + read once (2 x 0.9 GB), logits 131 MB x 5 touches,
     # Adam 28 B x 16 M parameters, features 51 MB, every weight matrix read twice (forward product, input gradient)
-    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=None, algorithmic_bytes=3.1e9,
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=2 * 6.99e9 + 4.16e9, algorithmic_bytes=3.1e9,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
@@ -298,6 +300,11 @@ def kernel_rooflines(trainer, model, audio_d, n_d, precision):
             out.append(_mfma_entry(f"decoder_sweep_fwd_kernel (attention + 2 LSTM cells, Hd={Hd}, B={B}, {U} steps x 4 dependent hand-offs "
                                    "in one launch)", fl, t, PEAK_F32_MFMA, bound="latency (reported against mfma)",
                                    us_per_dependent_step=round(t * 1e6 / U, 2)))
+            if getattr(ws, "dsweep_bwd_ws", None) is not None:
+                t = time_kernel(trainer.stream, lambda: model._decoder_sweep_bwd(ws), iters=5)
+                out.append(_mfma_entry(f"decoder_sweep_bwd_kernel (2 LSTM cells + attention backwards, Hd={Hd}, B={B}, {U} steps x 3 dependent "
+                                       "hand-offs in one launch)", 2.0 * fl, t, PEAK_F32_MFMA, bound="latency (reported against mfma)",
+                                       us_per_dependent_step=round(t * 1e6 / U, 2)))
     except Exception as e:   # never take the measured line down
         out.append({"kernel": "one-launch sweeps", "error": str(e)})
     return out
@@ -311,6 +318,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="las_small")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel timing loops (clean rocprof call counts)")
     ap.add_argument("--precision", choices=["f32", "bf16"], default=None,
                     help="default: f32 for las_small / deepspeech (the headline dtype), bf16 mixed precision for las_large (BASELINE configs[4])")
     args = ap.parse_args()
@@ -434,7 +442,7 @@ def main():
         # it is bound by the dependent-step latency of its recurrent sweeps (the kernels list says where the time goes)
         out["roofline"]["algorithmic_bytes"] = int(wl["algorithmic_bytes"])
         out["roofline"]["hbm_frac"] = round(wl["algorithmic_bytes"] / (dev_ms * 1e-3) / PEAK_HBM, 4)
-    if world == 1:
+    if world == 1 and not args.no_kernel_rooflines:
         try:
             out["roofline"]["kernels"] = kernel_rooflines(trainer, model, audio_d, n_d, precision)
         except Exception as e:  # per-kernel extras must never take the measured line down

@@ -20,5 +20,5 @@ PINNING STATUS
     gradient and optimizer value): **parity unpinned** - no reference test or golden
     vector holds a number for it and the TF reference cannot be executed in this image.
     The oracle is cross-checked against an independent second route (torch.nn.LSTM/GRU,
-    F.conv2d, torch.stft, F.ctc_loss) in tests/test_oracle_routes.py instead.
+    F.conv2d, torch.stft, F.ctc_loss) in tests/test_oracle.py instead.
 """

@@ -22,3 +22,11 @@ def t(fn, n=10):
     return e0.elapsed_time(e1) * 1e3 / n
 us = t(lambda: m._decoder_sweep(ws, True))
 print(f"decoder sweep: {us:.1f} us = {us / U:.2f} us/step (delay {os.environ.get('ASR_DECODER_SWEEP_DELAY', 'default')})")
+# backward sweep: needs the loss gradient in ws.dyd (any values do for timing)
+ws.dyd.normal_(0, 1e-3)
+m._decoder_sweep_bwd(ws)
+torch.cuda.synchronize()
+from speech_recognition_amd import ops
+assert not ops.decoder_sweep_error(ws.dsweep_bwd_ws), "backward sweep timed out"
+us = t(lambda: m._decoder_sweep_bwd(ws))
+print(f"decoder backward sweep: {us:.1f} us = {us / U:.2f} us/step (delay {os.environ.get('ASR_DECODER_SWEEP_BWD_DELAY', 'default')})")
