@@ -83,21 +83,20 @@ __device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile in
 }
 
 template <int CELL, int NT>      // NT: 16-unit tiles per unit group (KU = 16 NT)
-__global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
+__global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
   constexpr int NS = CELL == CELL_RNN ? 1 : 4;                      // saved / ds slots per unit
   constexpr int NGR = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);   // ds slots that multiply the recurrent kernel
   constexpr int KU = 16 * NT;                                       // units per unit group
-  constexpr int NL = KU * NGR;                                      // contraction labels (ds columns) of a workgroup
-  constexpr int KP = 4 / NT;                                        // contraction parts: publish wave = (tile, part)
-  constexpr int KPW = NL / 4 / KP;                                  // MFMA k-steps per publish wave (= NT * NT * NGR)
-  constexpr int LD = NL + 4;                                        // padded row of the ds image
-  __shared__ __attribute__((aligned(16))) float red[2][256][4];     // gather partial sums: [parity][thread][4 rows of a position]
-  __shared__ __attribute__((aligned(16))) float dsl[2][16][LD];     // ds of a step: [parity][row][label]
-  __shared__ __attribute__((aligned(16))) float sp[2][KP > 1 ? KP - 1 : 1][NT][256];   // contraction partials of the publish waves
-  __shared__ int abort_flag, g_done, o_done, s_cnt;
+  constexpr int UW = 4 * NT;                                        // units per gather wave (= its MFMA k-steps: one unit x 4 gate slots each)
+  constexpr int LP = 4 / NT;                                        // lanes that share a position (they split the senders)
+  constexpr int TRLD = 4 * UW + 4;                                  // padded row of a wave's ds image
+  __shared__ __attribute__((aligned(16))) float tr[4][16][TRLD];    // wave-private: ds of the wave's units, [row][unit * 4 + gate slot]
+  __shared__ __attribute__((aligned(16))) float part[2][4][NT][256];   // partial dh blocks of the gather waves (MFMA C layout), by step parity
+  __shared__ int abort_flag;
+  __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
   const SbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool go_wave = wv < 4;
+  const bool gather_wave = wv < 4;
   const int li = lane & 15, lq = lane >> 4;
   const int G = a.G, gi_ = blockIdx.x / G, gj_ = blockIdx.x % G;    // (i, j): ds of unit group i, partial dh of unit group j
   const int b0 = blockIdx.y * 16;
@@ -107,19 +106,18 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
   const long slot_floats = (long)G * G * blk;
   float* xb = a.xbuf + (long)group * SB_SLOTS * slot_floats;
   const int lds_limit = a.spin_limit > (1 << 20) ? a.spin_limit : (a.spin_limit << 4);   // LDS polls are ~16x shorter than fabric polls
-  if (tid == 0) { abort_flag = 0; g_done = 0; o_done = 0; s_cnt = 0; }
+  if (tid == 0) abort_flag = 0;
+  if (tid < 4) g_done[tid] = 0;
   __syncthreads();
 
-  if (go_wave) {
-    // ------------------------------------------------------------------------------------------ GATHER + OWNER
-    // row i of the exchange: G blocks x NT tiles x 64 pieces of 16 bytes; piece f = tid + 256 m -> sender f / (64 NT), position
-    // pos = f % (64 NT) = tid % (64 NT) for every m: (tile nt, lq, li): rows 4lq..4lq+3 of unit 16nt + li
-    constexpr int NPOS = 64 * NT;                                   // positions of a block
-    constexpr int TPP = 256 / NPOS;                                 // threads that share a position (= KP)
-    const int npieces = G * NPOS;
-    const int pos = tid % NPOS, sub = tid / NPOS;                   // this thread finishes rows sub * NT .. sub * NT + NT - 1 of the position
-    const int nt_ = pos >> 6, plq = (pos >> 4) & 3, pli = pos & 15;
-    const int un = 16 * nt_ + pli;                                  // unit inside the group
+  if (gather_wave) {
+    // ------------------------------------------------------------------------------------------ GATHER + GATE GRADIENTS + PRODUCT
+    // Wave w owns the units UW w .. UW w + UW - 1 of group i for all 16 rows.  Lane = (position pl, part): a position is one
+    // 16-byte piece of a block (rows 4 plq .. 4 plq + 3 of one unit); its LP lanes split the G senders and add up with two
+    // cross-lane shuffles (no LDS, no hand-over), then each finishes NT of the 4 rows.
+    const int pl = lane / LP, pt = lane % LP;
+    const int ul = pl >> 2, plq = pl & 3;                           // unit inside the wave, row quad
+    const int un = UW * wv + ul;                                    // unit inside the group
     const int j = gi_ * KU + un;                                    // hidden unit
     const bool writer = gj_ == 0;                                   // column 0 of the square writes the layer's outputs
     int brow[NT];
@@ -127,15 +125,23 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
     float dcv[NT], carry[NT], dirv[NT];
 #pragma unroll
     for (int r = 0; r < NT; ++r) {
-      brow[r] = b0 + 4 * plq + sub * NT + r;
+      brow[r] = b0 + 4 * plq + pt * NT + r;
       live[r] = brow[r] < B;
       dcv[r] = (live[r] && CELL == CELL_LSTM) ? d.dc[(long)brow[r] * H + j] : 0.f;
       carry[r] = 0.f; dirv[r] = 0.f;
     }
+    // resident B operands: k-step ks = unit ks of this wave, k-row lq = gate slot; the lane (li, lq) holds
+    // U[unit 16 t + li of group j][gate column lq of unit (UW w + ks) of group i]   (GRU: k-rows z, r, recurrent part of h~; row 3 unused)
+    float bwv[NT][UW];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < UW; ++ks)
+        bwv[t][ks] = lq < NGR ? d.U[(long)(gj_ * KU + 16 * t + li) * d.ldu + (long)lq * H + gi_ * KU + UW * wv + ks] : 0.f;
     const long row_off = (long)gi_ * G * blk;                       // row i inside a slot
-    // element-wise operands are fetched one step ahead: the loads for step p + 1 are issued as soon as the gather of step p has
-    // returned, so they travel while the gate math, the publish and the exchange round of step p run (a wave's loads retire in
-    // order: fetched at the top of their own step they would sit in front of the gather's polls)
+    const long pos_off = ((long)(un >> 4) * 64 + plq * 16 + (un & 15)) * 4;   // this position inside a block
+    // element-wise operands are fetched one step ahead (a wave's loads retire in order: fetched at the top of their own step they
+    // would sit in front of the gather's polls)
     struct Operands { bool m; float svv[NS], cpv, cov, hpv, dyv; };
     auto fetch = [&](int p, Operands (&o)[NT]) {
       const int step = T - 1 - p;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
         o[r].m = true; o[r].cpv = 0.f; o[r].cov = 0.f; o[r].hpv = 0.f; o[r].dyv = 0.f;
 #pragma unroll
         for (int g = 0; g < NS; ++g) o[r].svv[g] = 0.f;
-        if (live[r] && p < T) {
+        if (live[r] && p < T && !(a.dbg & 8)) {
           const long bt = (long)brow[r] * T + t;
           o[r].m = a.mask ? a.mask[bt] != 0 : true;
           const float* sv = d.saved + bt * NS * H + j;
@@ -175,11 +181,12 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
 #pragma unroll
       for (int r = 0; r < NT; ++r) sa[r] = 0.f;
       if (p > 0) {
-        const float* src = xb + (long)(p % SB_SLOTS) * slot_floats + row_off;
-        const float* p0 = src + (long)min(tid, npieces - 1) * 4;
-        const float* p1 = src + (long)min(tid + 256, npieces - 1) * 4;
-        const float* p2 = src + (long)min(tid + 512, npieces - 1) * 4;
-        const float* p3 = src + (long)min(tid + 768, npieces - 1) * 4;
+        const float* src = xb + (long)(p % SB_SLOTS) * slot_floats + row_off + pos_off;
+        const bool u0 = pt < G, u1 = pt + LP < G, u2 = pt + 2 * LP < G, u3 = pt + 3 * LP < G;
+        const float* p0 = src + (u0 ? (long)pt * blk : 0);
+        const float* p1 = src + (u1 ? (long)(pt + LP) * blk : 0);
+        const float* p2 = src + (u2 ? (long)(pt + 2 * LP) * blk : 0);
+        const float* p3 = src + (u3 ? (long)(pt + 3 * LP) * blk : 0);
         f32x4 v0, v1, v2, v3;
         int spins = 0;
         for (int w = 0; w < a.delay; ++w) __builtin_amdgcn_s_sleep(2);
@@ -196,11 +203,7 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
           auto fresh = [](const f32x4& v) {
             return __float_as_uint(v.x) != SB_SENT && __float_as_uint(v.y) != SB_SENT && __float_as_uint(v.z) != SB_SENT && __float_as_uint(v.w) != SB_SENT;
           };
-          bool ok = true;
-          if (tid < npieces) ok = ok && fresh(v0);
-          if (tid + 256 < npieces) ok = ok && fresh(v1);
-          if (tid + 512 < npieces) ok = ok && fresh(v2);
-          if (tid + 768 < npieces) ok = ok && fresh(v3);
+          const bool ok = (!u0 || fresh(v0)) && (!u1 || fresh(v1)) && (!u2 || fresh(v2)) && (!u3 || fresh(v3));
           if (__all(ok) || (a.dbg & 2)) break;
           if (*(volatile int*)&abort_flag) break;
           if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
@@ -208,19 +211,23 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
         }
         if (*(volatile int*)&abort_flag) break;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (tid < npieces) acc += v0;
-        if (tid + 256 < npieces) acc += v1;
-        if (tid + 512 < npieces) acc += v2;
-        if (tid + 768 < npieces) acc += v3;
-        *reinterpret_cast<f32x4*>(&red[p & 1][tid][0]) = acc;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&g_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!sb_wait(&g_done, 4 * p, &abort_flag, lds_limit, 2 | (p << 8))) break;
-        // the TPP threads that share this position hold partial sums over disjoint senders
+        if (u0) acc += v0;
+        if (u1) acc += v1;
+        if (u2) acc += v2;
+        if (u3) acc += v3;
+        // the LP lanes of the position hold sums over disjoint senders
 #pragma unroll
-        for (int k = 0; k < TPP; ++k)
+        for (int s2 = 1; s2 < LP; s2 <<= 1) {
+          acc.x += __shfl_xor(acc.x, s2, 64);
+          acc.y += __shfl_xor(acc.y, s2, 64);
+          acc.z += __shfl_xor(acc.z, s2, 64);
+          acc.w += __shfl_xor(acc.w, s2, 64);
+        }
 #pragma unroll
-          for (int r = 0; r < NT; ++r) sa[r] += red[p & 1][pos + k * NPOS][sub * NT + r];
+        for (int r = 0; r < NT; ++r) {
+          const int c = pt * NT + r;                                // component = row inside the quad
+          sa[r] = c == 0 ? acc.x : (c == 1 ? acc.y : (c == 2 ? acc.z : acc.w));
+        }
       }
       // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
       bool m[NT];
@@ -286,16 +293,34 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
         }
         break;
       }
-      // the labelled image of ds for the matrix product: label = gate slot gi * KU + unit  (GRU: gi 2 = slot 3)
+      // the wave's ds image in its own LDS rows, gate slots in the order the recurrent kernel's column blocks take them
+      // (GRU: z, r, r (.) d(a_hh); the input-side slot 2 does not multiply U), then read back as MFMA A operands: lane (li, lq) =
+      // (row, gate slot) of unit ks - the same wave wrote it, its LDS accesses execute in order
 #pragma unroll
-      for (int r = 0; r < NT; ++r)
+      for (int r = 0; r < NT; ++r) {
+        f32x4 img;
+        img.x = ds[r][0];
+        img.y = CELL == CELL_RNN ? 0.f : ds[r][1];
+        img.z = CELL == CELL_LSTM ? ds[r][2] : (CELL == CELL_GRU ? ds[r][3] : 0.f);
+        img.w = CELL == CELL_LSTM ? ds[r][3] : 0.f;
+        *reinterpret_cast<f32x4*>(&tr[wv][4 * plq + pt * NT + r][4 * ul]) = img;
+      }
+      f32x4 acc[NT];
 #pragma unroll
-        for (int gi = 0; gi < NGR; ++gi) dsl[p & 1][4 * plq + sub * NT + r][gi * KU + un] = ds[r][CELL == CELL_GRU && gi == 2 ? 3 : gi];
+      for (int t2 = 0; t2 < NT; ++t2) acc[t2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < UW; ++ks) {
+        const float av = tr[wv][li][4 * ks + lq];
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwv[t2][ks], acc[t2], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < NT; ++t2) *reinterpret_cast<f32x4*>(&part[p & 1][wv][t2][lane * 4]) = acc[t2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&o_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) *(volatile int*)&g_done[wv] = p + 1;
       // off the critical path from here: ds of the PREVIOUS step to `saved` (safe now: this step's gather has returned), then the
       // operands of the next step
-      if (writer && p > 0) {
+      if (writer && p > 0 && !(a.dbg & 16)) {
 #pragma unroll
         for (int r = 0; r < NT; ++r)
           if (live[r]) {
@@ -317,42 +342,27 @@ __global__ __launch_bounds__(512) void rnn_sweep_bwd_kernel(SbArgs a) {
         if (live[r]) d.dc[(long)brow[r] * H + j] = dcv[r];
     }
   } else {
-    // ------------------------------------------------------------------------------------------ PUBLISH
-    const int sw = wv - 4, nt_ = sw % NT, kp = sw / NT;             // output tile, contraction part
-    // B operands: k-step ks of this wave carries label cl = kp * 4 KPW + lq * KPW + ks  <->  (gate slot gi = cl / KU, unit cl % KU of
-    // group i); the lane (li, lq) holds U[unit 16 nt + li of group j][that column].  The labelling is free as long as A agrees.
-    float bwv[KPW];
-#pragma unroll
-    for (int ks = 0; ks < KPW; ++ks) {
-      const int cl = kp * 4 * KPW + lq * KPW + ks, gi = cl / KU, un = cl % KU;
-      bwv[ks] = d.U[(long)(gj_ * KU + 16 * nt_ + li) * d.ldu + (long)gi * H + gi_ * KU + un];   // LSTM i,f,c~,o; GRU z, r, recurrent part of h~
-    }
+    // ------------------------------------------------------------------------------------------ PUBLISH (one wave per output tile)
+    const int nt_ = wv - 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
     for (int p = 0; p < T; ++p) {
-      if (!sb_wait(&o_done, 4 * (p + 1), &abort_flag, lds_limit, 3 | (p << 8))) break;
-      float av[KPW];
-#pragma unroll
-      for (int ks = 0; ks < KPW; ++ks) av[ks] = dsl[p & 1][li][kp * 4 * KPW + lq * KPW + ks];
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KPW; ++ks) {
-        if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bwv[ks], acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bwv[ks], acc0, 0, 0, 0);
+      bool ok = true;
+      for (int i = 0;; ++i) {
+        const int v = *(volatile int*)&g_done[lane & 3];
+        if (__all(v >= p + 1)) break;
+        if (*(volatile int*)&abort_flag) { ok = false; break; }
+        if (i > lds_limit) { abort_flag = 3 | (p << 8); ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
       }
-      f32x4 acc = acc0 + acc1;                                       // acc[r] = partial dh[row 4lq + r][unit 16 nt + li of group j]
-      if (KP > 1) {
-        if (kp > 0) *reinterpret_cast<f32x4*>(&sp[p & 1][kp - 1][nt_][lane * 4]) = acc;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kp > 0) continue;
-        if (!sb_wait(&s_cnt, 4 * (p + 1), &abort_flag, lds_limit, 4 | (p << 8))) break;
-#pragma unroll
-        for (int k = 0; k < KP - 1; ++k) acc += *reinterpret_cast<const f32x4*>(&sp[p & 1][k][nt_][lane * 4]);
-      }
+      if (!ok) break;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(&part[p & 1][0][nt_][lane * 4]);
+      acc += *reinterpret_cast<const f32x4*>(&part[p & 1][1][nt_][lane * 4]);
+      acc += *reinterpret_cast<const f32x4*>(&part[p & 1][2][nt_][lane * 4]);
+      acc += *reinterpret_cast<const f32x4*>(&part[p & 1][3][nt_][lane * 4]);
       // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
       if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
@@ -402,7 +412,7 @@ static long sb_capacity(int rnn_type) {
     const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_LSTM, NT>)
                   : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_GRU, NT>)
                                          : reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_RNN, NT>);
-    cache[rnn_type] = asr_sweep_capacity(k, 512);
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + NT));
   }
   return cache[rnn_type];
 }
@@ -421,9 +431,9 @@ extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, in
 
 template <int NT>
 static void sb_launch(int rnn_type, dim3 grid, hipStream_t st, const SbArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(512), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(512), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_bwd (rnn_bwd.hip) in one launch.  gs->direct / gs->dy_carry are not used (those carries
