@@ -83,7 +83,7 @@ __device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile in
 }
 
 template <int CELL, int NT>      // NT: 16-unit tiles per unit group (KU = 16 NT)
-__global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
+__global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
   constexpr int NS = CELL == CELL_RNN ? 1 : 4;                      // saved / ds slots per unit
   constexpr int NGR = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);   // ds slots that multiply the recurrent kernel
   constexpr int KU = 16 * NT;                                       // units per unit group
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   __shared__ __attribute__((aligned(16))) float ops_s[2][16][KU][8];   // element-wise operands of a step, by step parity: {saved slots}, {c_out, c_prev | h_prev, dy, mask}
   __shared__ int abort_flag;
   __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
-  __shared__ int o_rdy[4];                                          // per memory wave: steps whose operands are in LDS
+  __shared__ int o_rdy[4];                                          // [0]: steps whose operands the fetch wave has put in LDS
   const SbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
@@ -207,8 +207,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       if (cell) {
         bool ok = true;
         for (int i = 0;; ++i) {
-          const int v = *(volatile int*)&o_rdy[lane % NT];
-          if (__all(v >= p + 1)) break;
+          if (*(volatile int*)&o_rdy[0] >= p + 1) break;
           if (*(volatile int*)&abort_flag) { ok = false; break; }
           if (i > lds_limit) { abort_flag = 2 | (p << 8); ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -299,67 +298,20 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       for (int r = 0; r < NT; ++r)
         if (live[r]) d.dc[(long)brow[r] * H + j] = dcv[r];
     }
-  } else {
-    // ------------------------------------------------------------------------------------------ MEMORY + PUBLISH (one wave per output tile)
-    // These waves own all of the kernel's memory traffic outside the gathers: they publish the partial-dh tile, load the
-    // element-wise operands of the step after next as coalesced float4 rows (lane = (batch row, 4 consecutive units)), hand them
-    // over through LDS, and write ds back over the saved activations one step late (only then is it certain that the other
-    // workgroups of the row - which read the same activations - have them in registers: they load a step's operands two steps
-    // ahead and wait for them before their previous publish, which this workgroup's next gather needs).
+  } else if (wv < 4 + NT) {
+    // ------------------------------------------------------------------------------------------ PUBLISH (one wave per output tile)
+    // Publishes the partial-dh tile and, in column 0 of the square, writes ds back over the saved activations ONE STEP LATE: only
+    // then is it certain that the other workgroups of the row - which read the same activations - have them on chip (their
+    // fetch waves hand a step's operands over before their gather waves can finish the previous step, and this workgroup's
+    // next gather needs that step's publishes).  Its stores are a step old when it waits for them before the next publish.
     const int nt_ = wv - 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
     const bool writer = gj_ == 0;
-    const int ml = nt_ * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
+    const int ml = nt_ * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);   // ds write-back: lane = (batch row, 4 consecutive units)
     const int mb = b0 + mrow, j0 = gi_ * KU + 4 * mq;
     const bool mlive = mb < B;
-    constexpr int NX = CELL == CELL_LSTM ? 2 : (CELL == CELL_GRU ? 1 : 0);      // state operands: (c_out, c_prev) | h_prev
-    f32x4 R[NS + NX + 1];
-    float Rm = 1.f;
-    auto mload = [&](int p) {
-#pragma unroll
-      for (int i = 0; i < NS + NX + 1; ++i) R[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      Rm = 1.f;
-      if (mlive && p < T) {
-        const int step = T - 1 - p;
-        const int t = d.reverse ? T - 1 - step : step;
-        const int tp = d.reverse ? t + 1 : t - 1;
-        const long bt = (long)mb * T + t;
-        Rm = a.mask ? (a.mask[bt] != 0 ? 1.f : 0.f) : 1.f;
-#pragma unroll
-        for (int g = 0; g < NS; ++g) R[g] = *reinterpret_cast<const f32x4*>(d.saved + bt * NS * H + (long)g * H + j0);
-        if (CELL == CELL_LSTM) {
-          R[NS] = *reinterpret_cast<const f32x4*>(d.cseq + bt * H + j0);
-          if (step == 0) { if (d.c0) R[NS + 1] = *reinterpret_cast<const f32x4*>(d.c0 + (long)mb * d.c0_ld + j0); }
-          else R[NS + 1] = *reinterpret_cast<const f32x4*>(d.cseq + ((long)mb * T + tp) * H + j0);
-        }
-        if (CELL == CELL_GRU) {
-          if (step == 0) { if (d.h0) R[NS] = *reinterpret_cast<const f32x4*>(d.h0 + (long)mb * d.h0_ld + j0); }
-          else R[NS] = *reinterpret_cast<const f32x4*>(d.hseq + ((long)mb * T + tp) * H + j0);
-        }
-        R[NS + NX] = *reinterpret_cast<const f32x4*>(a.dy + bt * a.dy_ld + d.y_col + j0);
-      }
-    };
-    auto mput = [&](int p) {                                         // R -> per-unit records of ops_s[p & 1]
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, Rm};
-        r0.x = R[0][e];
-        if (NS > 1) { r0.y = R[NS > 1 ? 1 : 0][e]; r0.z = R[NS > 2 ? 2 : 0][e]; r0.w = R[NS > 3 ? 3 : 0][e]; }
-        if (CELL == CELL_LSTM) { r1.x = R[NS][e]; r1.y = R[NS + (NX > 1 ? 1 : 0)][e]; }
-        if (CELL == CELL_GRU) r1.y = R[NS][e];
-        r1.z = R[NS + NX][e];
-        float* rec = &ops_s[p & 1][mrow][4 * mq + e][0];
-        *reinterpret_cast<f32x4*>(rec) = r0;
-        *reinterpret_cast<f32x4*>(rec + 4) = r1;
-      }
-    };
-    mload(0);
-    mput(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) *(volatile int*)&o_rdy[nt_] = 1;
-    mload(1);
     f32x4 dsv[NS];                                                   // ds of the previous step: [slot][4 units]
     int t_prev = 0;
     for (int p = 0; p < T; ++p) {
@@ -391,19 +343,14 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           if (CELL == CELL_GRU) { dcur[NS > 1 ? 1 : 0][e] = img.y; dcur[NS > 2 ? 2 : 0][e] = img.w; dcur[NS > 3 ? 3 : 0][e] = img.z; }
         }
       }
-      // retire what this wave issued a step ago (operand loads, ds stores, publish + sentinel), then publish and re-arm
+      // retire what this wave issued a step ago (ds stores, publish + sentinel), then publish and re-arm
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
       if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
       if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
-      // operands of step p + 1 (loaded a step ago) to LDS, loads for step p + 2, ds of step p - 1 to memory
-      mput(p + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *(volatile int*)&o_rdy[nt_] = p + 2;
-      mload(p + 2);
       if (writer) {
-        if (p > 0 && mlive) {
+        if (p > 0 && mlive && !(a.dbg & 16)) {
 #pragma unroll
           for (int g = 0; g < NS; ++g) *reinterpret_cast<f32x4*>(d.saved + ((long)mb * T + t_prev) * NS * H + (long)g * H + j0) = dsv[g];
         }
@@ -415,6 +362,80 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     if (writer && mlive && !*(volatile int*)&abort_flag) {             // the last step's ds
 #pragma unroll
       for (int g = 0; g < NS; ++g) *reinterpret_cast<f32x4*>(d.saved + ((long)mb * T + t_prev) * NS * H + (long)g * H + j0) = dsv[g];
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ FETCH (one wave)
+    // Streams the element-wise operands (saved gate activations, cell / hidden states, dy, mask) from memory into LDS, two steps
+    // in flight, as coalesced float4 rows: lane item = (batch row, 4 consecutive units).  Nobody waits for this wave's memory
+    // latency as long as it stays ahead; it is throttled by the two-deep LDS ring (ops_s[p & 1] is free once the gather waves
+    // have finished step p - 2).
+    constexpr int NX = CELL == CELL_LSTM ? 2 : (CELL == CELL_GRU ? 1 : 0);      // state operands: (c_out, c_prev) | h_prev
+    constexpr int NF = NS + NX + 1;
+    struct Batch { f32x4 v[NT][NF]; float m[NT]; };
+    auto load = [&](int p, Batch& q) {
+      const int pc = p < T ? p : T - 1;                              // (uniform control flow: clamped addresses instead of branches)
+      const int step = T - 1 - pc;
+      const int t = d.reverse ? T - 1 - step : step;
+      const int tp = d.reverse ? t + 1 : t - 1;
+#pragma unroll
+      for (int e = 0; e < NT; ++e) {
+        const int ml = e * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
+        const int mb = min(b0 + mrow, B - 1), j0 = gi_ * KU + 4 * mq;
+        const long bt = (long)mb * T + t;
+        q.m[e] = a.mask ? (a.mask[bt] != 0 ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) q.v[e][g] = *reinterpret_cast<const f32x4*>(d.saved + bt * NS * H + (long)g * H + j0);
+        if (CELL == CELL_LSTM) {
+          q.v[e][NS] = *reinterpret_cast<const f32x4*>(d.cseq + bt * H + j0);
+          if (step == 0) q.v[e][NS + (NX > 1 ? 1 : 0)] = d.c0 ? *reinterpret_cast<const f32x4*>(d.c0 + (long)mb * d.c0_ld + j0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          else q.v[e][NS + (NX > 1 ? 1 : 0)] = *reinterpret_cast<const f32x4*>(d.cseq + ((long)mb * T + tp) * H + j0);
+        }
+        if (CELL == CELL_GRU) {
+          if (step == 0) q.v[e][NS] = d.h0 ? *reinterpret_cast<const f32x4*>(d.h0 + (long)mb * d.h0_ld + j0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          else q.v[e][NS] = *reinterpret_cast<const f32x4*>(d.hseq + ((long)mb * T + tp) * H + j0);
+        }
+        q.v[e][NF - 1] = *reinterpret_cast<const f32x4*>(a.dy + bt * a.dy_ld + d.y_col + j0);
+      }
+    };
+    auto put = [&](int p, const Batch& q) -> bool {                  // batch -> per-unit records of ops_s[p & 1], once that buffer is free
+      if (p >= 2) {
+        for (int i = 0;; ++i) {
+          const int v = *(volatile int*)&g_done[lane & 3];
+          if (__all(v >= p - 1)) break;
+          if (*(volatile int*)&abort_flag) return false;
+          if (i > lds_limit) { abort_flag = 4 | (p << 8); return false; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NT; ++e) {
+        const int ml = e * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, q.m[e]};
+          r0.x = q.v[e][0][u];
+          if (NS > 1) { r0.y = q.v[e][NS > 1 ? 1 : 0][u]; r0.z = q.v[e][NS > 2 ? 2 : 0][u]; r0.w = q.v[e][NS > 3 ? 3 : 0][u]; }
+          if (CELL == CELL_LSTM) { r1.x = q.v[e][NS][u]; r1.y = q.v[e][NS + (NX > 1 ? 1 : 0)][u]; }
+          if (CELL == CELL_GRU) r1.y = q.v[e][NS][u];
+          r1.z = q.v[e][NF - 1][u];
+          float* rec = &ops_s[p & 1][mrow][4 * mq + u][0];
+          *reinterpret_cast<f32x4*>(rec) = r0;
+          *reinterpret_cast<f32x4*>(rec + 4) = r1;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *(volatile int*)&o_rdy[0] = p + 1;
+      return true;
+    };
+    Batch qa, qb;
+    load(0, qa);
+    load(1, qb);
+    for (int p = 0; p < T; p += 2) {
+      if (!put(p, qa)) break;
+      load(p + 2, qa);
+      if (p + 1 >= T) break;
+      if (!put(p + 1, qb)) break;
+      load(p + 3, qb);
     }
   }
   __syncthreads();
@@ -460,7 +481,7 @@ static long sb_capacity(int rnn_type) {
     const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_LSTM, NT>)
                   : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_GRU, NT>)
                                          : reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_RNN, NT>);
-    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + NT));
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (5 + NT));
   }
   return cache[rnn_type];
 }
@@ -479,9 +500,9 @@ extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, in
 
 template <int NT>
 static void sb_launch(int rnn_type, dim3 grid, hipStream_t st, const SbArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_bwd (rnn_bwd.hip) in one launch.  gs->direct / gs->dy_carry are not used (those carries
