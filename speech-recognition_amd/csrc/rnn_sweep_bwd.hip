@@ -83,7 +83,7 @@ __device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile in
 }
 
 template <int CELL, int NT>      // NT: 16-unit tiles per unit group (KU = 16 NT)
-__global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
+__global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
   constexpr int NS = CELL == CELL_RNN ? 1 : 4;                      // saved / ds slots per unit
   constexpr int NGR = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);   // ds slots that multiply the recurrent kernel
   constexpr int KU = 16 * NT;                                       // units per unit group
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   __shared__ __attribute__((aligned(16))) float ops_s[2][16][KU][8];   // element-wise operands of a step, by step parity: {saved slots}, {c_out, c_prev | h_prev, dy, mask}
   __shared__ int abort_flag;
   __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
-  __shared__ int o_rdy[4];                                          // [0]: steps whose operands the fetch wave has put in LDS
+  __shared__ int o_rdy[4];                                          // per fetch wave: steps whose operands it has put in LDS
   const SbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       if (cell) {
         bool ok = true;
         for (int i = 0;; ++i) {
-          if (*(volatile int*)&o_rdy[0] >= p + 1) break;
+          const int v = *(volatile int*)&o_rdy[lane % NT];
+          if (__all(v >= p + 1)) break;
           if (*(volatile int*)&abort_flag) { ok = false; break; }
           if (i > lds_limit) { abort_flag = 2 | (p << 8); ok = false; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -364,22 +365,23 @@ __global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       for (int g = 0; g < NS; ++g) *reinterpret_cast<f32x4*>(d.saved + ((long)mb * T + t_prev) * NS * H + (long)g * H + j0) = dsv[g];
     }
   } else {
-    // ------------------------------------------------------------------------------------------ FETCH (one wave)
+    // ------------------------------------------------------------------------------------------ FETCH (one wave per 64 (row, unit quad) items)
+    const int fw = wv - 4 - NT;
     // Streams the element-wise operands (saved gate activations, cell / hidden states, dy, mask) from memory into LDS, two steps
     // in flight, as coalesced float4 rows: lane item = (batch row, 4 consecutive units).  Nobody waits for this wave's memory
     // latency as long as it stays ahead; it is throttled by the two-deep LDS ring (ops_s[p & 1] is free once the gather waves
     // have finished step p - 2).
     constexpr int NX = CELL == CELL_LSTM ? 2 : (CELL == CELL_GRU ? 1 : 0);      // state operands: (c_out, c_prev) | h_prev
     constexpr int NF = NS + NX + 1;
-    struct Batch { f32x4 v[NT][NF]; float m[NT]; };
+    struct Batch { f32x4 v[1][NF]; float m[1]; };
     auto load = [&](int p, Batch& q) {
       const int pc = p < T ? p : T - 1;                              // (uniform control flow: clamped addresses instead of branches)
       const int step = T - 1 - pc;
       const int t = d.reverse ? T - 1 - step : step;
       const int tp = d.reverse ? t + 1 : t - 1;
-#pragma unroll
-      for (int e = 0; e < NT; ++e) {
-        const int ml = e * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
+      {
+        constexpr int e = 0;
+        const int ml = fw * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
         const int mb = min(b0 + mrow, B - 1), j0 = gi_ * KU + 4 * mq;
         const long bt = (long)mb * T + t;
         q.m[e] = a.mask ? (a.mask[bt] != 0 ? 1.f : 0.f) : 1.f;
@@ -407,9 +409,9 @@ __global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           __builtin_amdgcn_s_sleep(2);
         }
       }
-#pragma unroll
-      for (int e = 0; e < NT; ++e) {
-        const int ml = e * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
+      {
+        constexpr int e = 0;
+        const int ml = fw * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, q.m[e]};
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64 * (5 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *(volatile int*)&o_rdy[0] = p + 1;
+      if (lane == 0) *(volatile int*)&o_rdy[fw] = p + 1;
       return true;
     };
     Batch qa, qb;
@@ -481,7 +483,7 @@ static long sb_capacity(int rnn_type) {
     const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_LSTM, NT>)
                   : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_GRU, NT>)
                                          : reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_RNN, NT>);
-    cache[rnn_type] = asr_sweep_capacity(k, 64 * (5 + NT));
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + 2 * NT));
   }
   return cache[rnn_type];
 }
@@ -500,9 +502,9 @@ extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, in
 
 template <int NT>
 static void sb_launch(int rnn_type, dim3 grid, hipStream_t st, const SbArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (5 + NT)), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_bwd (rnn_bwd.hip) in one launch.  gs->direct / gs->dy_carry are not used (those carries
