@@ -83,7 +83,7 @@ __device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile in
 }
 
 template <int CELL, int NT>      // NT: 16-unit tiles per unit group (KU = 16 NT)
-__global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
+__global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) {
   constexpr int NS = CELL == CELL_RNN ? 1 : 4;                      // saved / ds slots per unit
   constexpr int NGR = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);   // ds slots that multiply the recurrent kernel
   constexpr int KU = 16 * NT;                                       // units per unit group
@@ -92,10 +92,8 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
   constexpr int TRLD = 4 * UW + 4;                                  // padded row of a wave's ds image
   __shared__ __attribute__((aligned(16))) float tr[4][16][TRLD];    // wave-private: ds of the wave's units, [row][unit * 4 + gate slot]
   __shared__ __attribute__((aligned(16))) float part[2][4][NT][256];   // partial dh blocks of the gather waves (MFMA C layout), by step parity
-  __shared__ __attribute__((aligned(16))) float ops_s[2][16][KU][8];   // element-wise operands of a step, by step parity: {saved slots}, {c_out, c_prev | h_prev, dy, mask}
   __shared__ int abort_flag;
   __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
-  __shared__ int o_rdy[4];                                          // per fetch wave: steps whose operands it has put in LDS
   const SbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
@@ -109,7 +107,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
   float* xb = a.xbuf + (long)group * SB_SLOTS * slot_floats;
   const int lds_limit = a.spin_limit > (1 << 20) ? a.spin_limit : (a.spin_limit << 4);   // LDS polls are ~16x shorter than fabric polls
   if (tid == 0) abort_flag = 0;
-  if (tid < 4) { g_done[tid] = 0; o_rdy[tid] = 0; }
+  if (tid < 4) g_done[tid] = 0;
   __syncthreads();
 
   if (gather_wave) {
@@ -142,10 +140,39 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
         bwv[t][ks] = lq < NGR ? d.U[(long)(gj_ * KU + 16 * t + li) * d.ldu + (long)lq * H + gi_ * KU + UW * wv + ks] : 0.f;
     const long row_off = (long)gi_ * G * blk;                       // row i inside a slot
     const long pos_off = ((long)(un >> 4) * 64 + plq * 16 + (un & 15)) * 4;   // this position inside a block
-    // The element-wise operands of a step come from LDS, where the memory waves put them a step ahead: a gather wave never loads
-    // from HBM inside the loop.  (A wave's loads retire in order, so operand loads issued behind the product sat in front of the
-    // next gather's polls and made them wait for an HBM round trip: 3.2 us of local work per step with the waits switched off,
-    // 2.4 without the loads; issued ahead of the gate math they delay the publish instead.)
+    // element-wise operands are fetched one step ahead (a wave's loads retire in order: fetched at the top of their own step they
+    // would sit in front of the gather's polls)
+    struct Operands { bool m; float svv[NS], cpv, cov, hpv, dyv; };
+    auto fetch = [&](int p, Operands (&o)[NT]) {
+      const int step = T - 1 - p;
+      const int t = d.reverse ? T - 1 - step : step;
+      const int tp = d.reverse ? t + 1 : t - 1;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        o[r].m = true; o[r].cpv = 0.f; o[r].cov = 0.f; o[r].hpv = 0.f; o[r].dyv = 0.f;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) o[r].svv[g] = 0.f;
+        if (live[r] && p < T && !(a.dbg & 8)) {
+          const long bt = (long)brow[r] * T + t;
+          o[r].m = a.mask ? a.mask[bt] != 0 : true;
+          const float* sv = d.saved + bt * NS * H + j;
+#pragma unroll
+          for (int g = 0; g < NS; ++g) o[r].svv[g] = sv[(long)g * H];
+          o[r].dyv = a.dy[bt * a.dy_ld + d.y_col + j];
+          if (CELL == CELL_LSTM) {
+            o[r].cov = d.cseq[bt * H + j];
+            o[r].cpv = step == 0 ? (d.c0 ? d.c0[(long)brow[r] * d.c0_ld + j] : 0.f) : d.cseq[((long)brow[r] * T + tp) * H + j];
+          }
+          if (CELL == CELL_GRU) o[r].hpv = step == 0 ? (d.h0 ? d.h0[(long)brow[r] * d.h0_ld + j] : 0.f) : d.hseq[((long)brow[r] * T + tp) * H + j];
+        }
+      }
+    };
+    Operands nxt[NT];
+    fetch(0, nxt);
+    // ds of the previous step, written to `saved` one step late: the other workgroups of this row read the same saved
+    // activations, and only when the gather of step p + 1 has returned is it certain that all of them have finished step p
+    float dsp[NT][NS];
+    int t_prev = 0;
     for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
       const bool cell = p < T;
       const int step = T - 1 - p;
@@ -202,27 +229,14 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
           sa[r] = c == 0 ? acc.x : (c == 1 ? acc.y : (c == 2 ? acc.z : acc.w));
         }
       }
+      // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
       bool m[NT];
       float svv[NT][NS], cpv[NT], cov[NT], hpv[NT], dyv[NT], addAv[NT];
-      if (cell) {
-        bool ok = true;
-        for (int i = 0;; ++i) {
-          const int v = *(volatile int*)&o_rdy[lane % NT];
-          if (__all(v >= p + 1)) break;
-          if (*(volatile int*)&abort_flag) { ok = false; break; }
-          if (i > lds_limit) { abort_flag = 2 | (p << 8); ok = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) break;
-      }
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        const float* rec = &ops_s[p & 1][4 * plq + pt * NT + r][un][0];
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rec), r1 = *reinterpret_cast<const f32x4*>(rec + 4);
-        svv[r][0] = r0.x;
-        if (NS > 1) { svv[r][NS > 1 ? 1 : 0] = r0.y; svv[r][NS > 2 ? 2 : 0] = r0.z; svv[r][NS > 3 ? 3 : 0] = r0.w; }
-        cov[r] = r1.x; cpv[r] = r1.y; hpv[r] = r1.y; dyv[r] = r1.z; m[r] = r1.w != 0.f;
-        addAv[r] = 0.f;
+        m[r] = nxt[r].m; cpv[r] = nxt[r].cpv; cov[r] = nxt[r].cov; hpv[r] = nxt[r].hpv; dyv[r] = nxt[r].dyv; addAv[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) svv[r][g] = nxt[r].svv[g];
         if (p == 0 && live[r] && d.dh_last) addAv[r] = d.dh_last[(long)brow[r] * d.dh_last_ld + j];
       }
       float ds[NT][4];
@@ -267,7 +281,18 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
           dirv[r] = dir;
         }
       }
-      if (!cell) break;
+      if (!cell) {
+        if (writer) {                                               // the last step's ds (its gather has returned)
+#pragma unroll
+          for (int r = 0; r < NT; ++r)
+            if (live[r]) {
+              float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
+#pragma unroll
+              for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
+            }
+        }
+        break;
+      }
       // the wave's ds image in its own LDS rows, gate slots in the order the recurrent kernel's column blocks take them
       // (GRU: z, r, r (.) d(a_hh); the input-side slot 2 does not multiply U), then read back as MFMA A operands: lane (li, lq) =
       // (row, gate slot) of unit ks - the same wave wrote it, its LDS accesses execute in order
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
         img.x = ds[r][0];
         img.y = CELL == CELL_RNN ? 0.f : ds[r][1];
         img.z = CELL == CELL_LSTM ? ds[r][2] : (CELL == CELL_GRU ? ds[r][3] : 0.f);
-        img.w = CELL == CELL_LSTM ? ds[r][3] : (CELL == CELL_GRU ? ds[r][2] : 0.f);   // (GRU: k-row 3 has zero weights; the slot carries d(a_hh) to the memory waves)
+        img.w = CELL == CELL_LSTM ? ds[r][3] : 0.f;
         *reinterpret_cast<f32x4*>(&tr[wv][4 * plq + pt * NT + r][4 * ul]) = img;
       }
       f32x4 acc[NT];
@@ -293,31 +318,36 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
       for (int t2 = 0; t2 < NT; ++t2) *reinterpret_cast<f32x4*>(&part[p & 1][wv][t2][lane * 4]) = acc[t2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) *(volatile int*)&g_done[wv] = p + 1;
+      // off the critical path from here: ds of the PREVIOUS step to `saved` (safe now: this step's gather has returned), then the
+      // operands of the next step
+      if (writer && p > 0 && !(a.dbg & 16)) {
+#pragma unroll
+        for (int r = 0; r < NT; ++r)
+          if (live[r]) {
+            float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
+#pragma unroll
+            for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
+          }
+      }
+      fetch(p + 1, nxt);
+      t_prev = t;
+#pragma unroll
+      for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int g = 0; g < NS; ++g) dsp[r][g] = ds[r][g];
     }
     if (writer && CELL == CELL_LSTM && !abort_flag) {
 #pragma unroll
       for (int r = 0; r < NT; ++r)
         if (live[r]) d.dc[(long)brow[r] * H + j] = dcv[r];
     }
-  } else if (wv < 4 + NT) {
+  } else {
     // ------------------------------------------------------------------------------------------ PUBLISH (one wave per output tile)
-    // Publishes the partial-dh tile and, in column 0 of the square, writes ds back over the saved activations ONE STEP LATE: only
-    // then is it certain that the other workgroups of the row - which read the same activations - have them on chip (their
-    // fetch waves hand a step's operands over before their gather waves can finish the previous step, and this workgroup's
-    // next gather needs that step's publishes).  Its stores are a step old when it waits for them before the next publish.
     const int nt_ = wv - 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
-    const bool writer = gj_ == 0;
-    const int ml = nt_ * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);   // ds write-back: lane = (batch row, 4 consecutive units)
-    const int mb = b0 + mrow, j0 = gi_ * KU + 4 * mq;
-    const bool mlive = mb < B;
-    f32x4 dsv[NS];                                                   // ds of the previous step: [slot][4 units]
-    int t_prev = 0;
     for (int p = 0; p < T; ++p) {
-      const int step = T - 1 - p;
-      const int t = d.reverse ? T - 1 - step : step;
       bool ok = true;
       for (int i = 0;; ++i) {
         const int v = *(volatile int*)&g_done[lane & 3];
@@ -331,113 +361,12 @@ __global__ __launch_bounds__(64 * (4 + 2 * NT)) void rnn_sweep_bwd_kernel(SbArgs
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][1][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][2][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][3][nt_][lane * 4]);
-      // this step's ds of the lane's (row, 4 units), out of the gather waves' images (before the publish: they are rewritten after
-      // the next gather, which waits for it)
-      f32x4 dcur[NS];
-      if (writer) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int u = 4 * mq + e;
-          const f32x4 img = *reinterpret_cast<const f32x4*>(&tr[u / UW][mrow][4 * (u % UW)]);
-          dcur[0][e] = img.x;
-          if (CELL == CELL_LSTM) { dcur[NS > 1 ? 1 : 0][e] = img.y; dcur[NS > 2 ? 2 : 0][e] = img.z; dcur[NS > 3 ? 3 : 0][e] = img.w; }
-          if (CELL == CELL_GRU) { dcur[NS > 1 ? 1 : 0][e] = img.y; dcur[NS > 2 ? 2 : 0][e] = img.w; dcur[NS > 3 ? 3 : 0][e] = img.z; }
-        }
-      }
-      // retire what this wave issued a step ago (ds stores, publish + sentinel), then publish and re-arm
+      // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
       if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
       if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
-      if (writer) {
-        if (p > 0 && mlive && !(a.dbg & 16)) {
-#pragma unroll
-          for (int g = 0; g < NS; ++g) *reinterpret_cast<f32x4*>(d.saved + ((long)mb * T + t_prev) * NS * H + (long)g * H + j0) = dsv[g];
-        }
-#pragma unroll
-        for (int g = 0; g < NS; ++g) dsv[g] = dcur[g];
-      }
-      t_prev = t;
-    }
-    if (writer && mlive && !*(volatile int*)&abort_flag) {             // the last step's ds
-#pragma unroll
-      for (int g = 0; g < NS; ++g) *reinterpret_cast<f32x4*>(d.saved + ((long)mb * T + t_prev) * NS * H + (long)g * H + j0) = dsv[g];
-    }
-  } else {
-    // ------------------------------------------------------------------------------------------ FETCH (one wave per 64 (row, unit quad) items)
-    const int fw = wv - 4 - NT;
-    // Streams the element-wise operands (saved gate activations, cell / hidden states, dy, mask) from memory into LDS, two steps
-    // in flight, as coalesced float4 rows: lane item = (batch row, 4 consecutive units).  Nobody waits for this wave's memory
-    // latency as long as it stays ahead; it is throttled by the two-deep LDS ring (ops_s[p & 1] is free once the gather waves
-    // have finished step p - 2).
-    constexpr int NX = CELL == CELL_LSTM ? 2 : (CELL == CELL_GRU ? 1 : 0);      // state operands: (c_out, c_prev) | h_prev
-    constexpr int NF = NS + NX + 1;
-    struct Batch { f32x4 v[1][NF]; float m[1]; };
-    auto load = [&](int p, Batch& q) {
-      const int pc = p < T ? p : T - 1;                              // (uniform control flow: clamped addresses instead of branches)
-      const int step = T - 1 - pc;
-      const int t = d.reverse ? T - 1 - step : step;
-      const int tp = d.reverse ? t + 1 : t - 1;
-      {
-        constexpr int e = 0;
-        const int ml = fw * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
-        const int mb = min(b0 + mrow, B - 1), j0 = gi_ * KU + 4 * mq;
-        const long bt = (long)mb * T + t;
-        q.m[e] = a.mask ? (a.mask[bt] != 0 ? 1.f : 0.f) : 1.f;
-#pragma unroll
-        for (int g = 0; g < NS; ++g) q.v[e][g] = *reinterpret_cast<const f32x4*>(d.saved + bt * NS * H + (long)g * H + j0);
-        if (CELL == CELL_LSTM) {
-          q.v[e][NS] = *reinterpret_cast<const f32x4*>(d.cseq + bt * H + j0);
-          if (step == 0) q.v[e][NS + (NX > 1 ? 1 : 0)] = d.c0 ? *reinterpret_cast<const f32x4*>(d.c0 + (long)mb * d.c0_ld + j0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          else q.v[e][NS + (NX > 1 ? 1 : 0)] = *reinterpret_cast<const f32x4*>(d.cseq + ((long)mb * T + tp) * H + j0);
-        }
-        if (CELL == CELL_GRU) {
-          if (step == 0) q.v[e][NS] = d.h0 ? *reinterpret_cast<const f32x4*>(d.h0 + (long)mb * d.h0_ld + j0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          else q.v[e][NS] = *reinterpret_cast<const f32x4*>(d.hseq + ((long)mb * T + tp) * H + j0);
-        }
-        q.v[e][NF - 1] = *reinterpret_cast<const f32x4*>(a.dy + bt * a.dy_ld + d.y_col + j0);
-      }
-    };
-    auto put = [&](int p, const Batch& q) -> bool {                  // batch -> per-unit records of ops_s[p & 1], once that buffer is free
-      if (p >= 2) {
-        for (int i = 0;; ++i) {
-          const int v = *(volatile int*)&g_done[lane & 3];
-          if (__all(v >= p - 1)) break;
-          if (*(volatile int*)&abort_flag) return false;
-          if (i > lds_limit) { abort_flag = 4 | (p << 8); return false; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      {
-        constexpr int e = 0;
-        const int ml = fw * 64 + lane, mrow = ml / (4 * NT), mq = ml % (4 * NT);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, q.m[e]};
-          r0.x = q.v[e][0][u];
-          if (NS > 1) { r0.y = q.v[e][NS > 1 ? 1 : 0][u]; r0.z = q.v[e][NS > 2 ? 2 : 0][u]; r0.w = q.v[e][NS > 3 ? 3 : 0][u]; }
-          if (CELL == CELL_LSTM) { r1.x = q.v[e][NS][u]; r1.y = q.v[e][NS + (NX > 1 ? 1 : 0)][u]; }
-          if (CELL == CELL_GRU) r1.y = q.v[e][NS][u];
-          r1.z = q.v[e][NF - 1][u];
-          float* rec = &ops_s[p & 1][mrow][4 * mq + u][0];
-          *reinterpret_cast<f32x4*>(rec) = r0;
-          *reinterpret_cast<f32x4*>(rec + 4) = r1;
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *(volatile int*)&o_rdy[fw] = p + 1;
-      return true;
-    };
-    Batch qa, qb;
-    load(0, qa);
-    load(1, qb);
-    for (int p = 0; p < T; p += 2) {
-      if (!put(p, qa)) break;
-      load(p + 2, qa);
-      if (p + 1 >= T) break;
-      if (!put(p + 1, qb)) break;
-      load(p + 3, qb);
     }
   }
   __syncthreads();
@@ -483,7 +412,7 @@ static long sb_capacity(int rnn_type) {
     const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_LSTM, NT>)
                   : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_GRU, NT>)
                                          : reinterpret_cast<const void*>(rnn_sweep_bwd_kernel<CELL_RNN, NT>);
-    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + 2 * NT));
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + NT));
   }
   return cache[rnn_type];
 }
@@ -502,9 +431,9 @@ extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, in
 
 template <int NT>
 static void sb_launch(int rnn_type, dim3 grid, hipStream_t st, const SbArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (4 + 2 * NT)), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_LSTM, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_GRU, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_bwd_kernel<CELL_RNN, NT>), grid, dim3(64 * (4 + NT)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_bwd (rnn_bwd.hip) in one launch.  gs->direct / gs->dy_carry are not used (those carries
@@ -531,16 +460,11 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   // see rnn_sweep.hip; the owner math sits between a gather and the next publish here, so less of the round is dead time
   // (las_small: 4.04 us per step with no delay, 3.13 with 8 x 128 cycles, 3.33 with 12)
-  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 8;
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 6;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
-    // the memory waves move the element-wise operands as float4 rows of four consecutive units
-    auto al16 = [](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && ld % 4 == 0); };
-    ASR_CHECK(al16(s->saved[d], 4) && al16(s->hseq[d], 4) && al16(s->cseq[d], 4) && al16(s->h0[d], s->h0_ld[d]) && al16(s->c0[d], s->c0_ld[d]) &&
-                  al16(gs->dy, gs->dy_ld) && s->y_col[d] % 4 == 0,
-              ASR_ERR_ARG, "asr_rnn_sweep_bwd: saved / hseq / cseq / h0 / c0 / dy rows must be 16-byte aligned (dir %d)", d);
     SbDir& p = a.d[d];
     p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.saved = s->saved[d]; p.hseq = s->hseq[d]; p.cseq = s->cseq[d];
     p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
