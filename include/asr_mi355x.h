@@ -371,6 +371,15 @@ int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws
 void asr_rnn_sweep_set_spin_limit(int polls);
 int asr_rnn_sweep_spin_limit(void);
 
+/* Wide layers under mixed precision (las_large: H = 1024, B = 64): one launch per layer with the recurrent kernel resident as
+ * bf16 MFMA operands (64 KB per workgroup, one workgroup of 8 hidden units per compute unit and direction), h_t exchanged as bf16
+ * pieces that are the next step's A operands; same contract as asr_rnn_seq_fwd with the state operand of the recurrent product
+ * rounded to bf16 (as the wide step kernels do with bf16 weights).  LSTM, 256 < H <= 1024, H % 128 == 0 (H / 128 in {4, 6, 8}),
+ * B <= 64, H / 8 * ndir <= compute units.  ws: asr_rnn_sweep_wide_ws_floats() floats; error word / err_flag as asr_rnn_sweep_fwd. */
+int asr_rnn_sweep_wide_supported(int rnn_type, int B, int T, int H, int ndir);
+long asr_rnn_sweep_wide_ws_floats(int B, int H, int ndir);
+int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * One-launch forward sweep of the LAS decoder under teacher forcing (las.py:267-292 looped by las.py:368-377): all U steps of
  * {attention, decoder LSTM 0, decoder LSTM 1} in one kernel (decoder_sweep.hip) - replaces U x {asr_attn_step_fwd,

@@ -18,6 +18,7 @@ import os
 
 # ASR_PERSISTENT_RNN=0 forces the one-launch-per-step recurrent kernels (debugging / A-B timing)
 PERSISTENT_RNN = os.environ.get("ASR_PERSISTENT_RNN", "1") != "0"
+WIDE_SWEEP = os.environ.get("ASR_WIDE_SWEEP", "1") != "0"      # the bf16 weights-resident forward sweep of wide layers (mixed precision)
 
 NG = {"lstm": 4, "gru": 3, "rnn": 1}   # gates in the Keras kernel layout
 NS = {"lstm": 4, "gru": 4, "rnn": 1}   # columns saved per unit by the cell kernels ("slots")
@@ -224,6 +225,11 @@ class BiRNN:
             if "persist_ws" not in buf:
                 buf["persist_ws"] = ops.rnn_persist_ws(B, H, 2, x3d.device)
             ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"], getattr(self.store, "err_flag", None))
+        elif PERSISTENT_RNN and WIDE_SWEEP and not rdrop and ops.rnn_sweep_wide_supported(rt, B, T, H, 2) and \
+                torch.cuda.get_device_properties(x3d.device).multi_processor_count >= H // 4:
+            if "wide_ws" not in buf:
+                buf["wide_ws"] = ops.rnn_sweep_wide_ws(B, H, 2, x3d.device)
+            ops.rnn_sweep_wide_fwd(buf["seq"], buf["wide_ws"], getattr(self.store, "err_flag", None))
         else:
             ops.rnn_seq_fwd(buf["seq"])
         return buf["y"]

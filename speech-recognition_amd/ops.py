@@ -431,6 +431,19 @@ def rnn_seq_fwd_persist(seq, ws, err_flag=None):
     check(lib().asr_rnn_sweep_fwd(C.byref(seq), _p(ws), _p(err_flag), _stream()))
 
 
+def rnn_sweep_wide_supported(rnn_type, B, T, H, ndir=2) -> bool:
+    """True when the wide one-launch forward sweep (rnn_sweep_wide.hip: bf16 weights resident, mixed precision) takes this layer."""
+    return mixed_precision() and bool(lib().asr_rnn_sweep_wide_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+
+
+def rnn_sweep_wide_ws(B, H, ndir=2, device="cuda"):
+    return torch.zeros(int(lib().asr_rnn_sweep_wide_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
+
+
+def rnn_sweep_wide_fwd(seq, ws, err_flag=None):
+    check(lib().asr_rnn_sweep_wide_fwd(C.byref(seq), _p(ws), _p(err_flag), _stream()))
+
+
 def rnn_persist_error(ws) -> int:
     """Non-zero if a hand-off of the last one-launch sweep timed out (synchronises): (who gave up | step << 8)."""
     return int(ws[-32:].view(torch.int32)[0].item())

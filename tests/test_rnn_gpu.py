@@ -249,3 +249,41 @@ def test_wide_step_kernels_mixed_precision(rt, B, T, D, H):
         a, b = res[False][1][k], res[True][1][k]
         scale = max(1e-3, float(a.abs().max()))
         assert float((a - b).abs().max()) < 5e-2 * scale, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("B,T,H,masked,init", [(40, 14, 512, True, True), (64, 9, 1024, False, False), (18, 11, 768, True, False)])
+def test_wide_sweep_equals_wide_step_kernels_mixed_precision(B, T, H, masked, init):
+    """The weights-resident bf16 forward sweep of wide LSTM layers (rnn_sweep_wide.hip: las_large) against the wide step kernels
+    under mixed precision, same layer and inputs: both round the recurrent kernel and the state operand to bf16 and accumulate
+    in f32, so outputs, states and saved gate activations agree to f32 summation order (2e-4 of the largest entry over these
+    short sequences)."""
+    from speech_recognition_amd import ops
+    from tests.rnn_helpers import HipBiRNN
+    ops.set_mixed_precision(True)
+    try:
+        g = torch.Generator().manual_seed(H + B)
+        fwd, bwd = make_params("lstm", 24, H, g, 0.03)
+        x = torch.randn(B, T, 24, generator=g, dtype=torch.float64)
+        mask = None
+        if masked:
+            mask = torch.ones(B, T, dtype=torch.bool)
+            mask[1, T // 2:] = False
+            mask[B - 1, 3:5] = False
+            mask[B // 2, :2] = False
+        init_states = [torch.randn(B, H, generator=g) * 0.3 for _ in range(4)] if init else None
+        outs = []
+        for wide in (True, False):
+            hip = HipBiRNN("lstm", x, mask, fwd, bwd, init_states)
+            if wide:
+                assert ops.rnn_sweep_wide_supported("lstm", B, T, H, 2)
+                ws = ops.rnn_sweep_wide_ws(B, H, 2)
+                ops.rnn_sweep_wide_fwd(hip.seq, ws)
+                torch.cuda.synchronize()
+                assert not ops.rnn_persist_error(ws), "wide sweep: a hand-off timed out"
+            else:
+                ops.rnn_seq_fwd(hip.seq)
+            outs.append(dict(y=hip.y.clone(), **{f"{k}{d}": dd[k].clone() for d, dd in enumerate(hip.dirs) for k in ("hseq", "cseq", "saved")}))
+        for k, ref in outs[1].items():
+            assert_close(outs[0][k], ref, 2e-4, k)
+    finally:
+        ops.set_mixed_precision(False)
