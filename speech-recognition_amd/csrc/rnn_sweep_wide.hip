@@ -353,9 +353,9 @@ extern "C" int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* er
   const size_t smem = sizeof(float) * 2 * 4 * 4 * 2 * 16 * 17 + (size_t)4 * ks * 2 * 64 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr = true;
   }
   if (ks == 8) hipLaunchKernelGGL(rnn_sweepw_fwd_kernel<8>, grid, dim3(384), smem, st, a);

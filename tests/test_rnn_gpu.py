@@ -255,8 +255,8 @@ def test_wide_step_kernels_mixed_precision(rt, B, T, D, H):
 def test_wide_sweep_equals_wide_step_kernels_mixed_precision(B, T, H, masked, init):
     """The weights-resident bf16 forward sweep of wide LSTM layers (rnn_sweep_wide.hip: las_large) against the wide step kernels
     under mixed precision, same layer and inputs: both round the recurrent kernel and the state operand to bf16 and accumulate
-    in f32, so outputs, states and saved gate activations agree to f32 summation order (2e-4 of the largest entry over these
-    short sequences)."""
+    in f32; the two differ in summation order, which now and then moves an h value across a bf16 rounding boundary of the next
+    step's operand (2^-9 relative): outputs, states and saved gate activations within 1e-3 of the largest entry."""
     from speech_recognition_amd import ops
     from tests.rnn_helpers import HipBiRNN
     ops.set_mixed_precision(True)
@@ -284,6 +284,6 @@ def test_wide_sweep_equals_wide_step_kernels_mixed_precision(B, T, H, masked, in
                 ops.rnn_seq_fwd(hip.seq)
             outs.append(dict(y=hip.y.clone(), **{f"{k}{d}": dd[k].clone() for d, dd in enumerate(hip.dirs) for k in ("hseq", "cseq", "saved")}))
         for k, ref in outs[1].items():
-            assert_close(outs[0][k], ref, 2e-4, k)
+            assert_close(outs[0][k], ref, 1e-3, k)
     finally:
         ops.set_mixed_precision(False)

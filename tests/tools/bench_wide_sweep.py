@@ -1,0 +1,24 @@
+"""Time the wide (bf16 weights-resident) forward sweep against the wide step kernels on the las_large layer (B=64, T'=499, H=1024)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+
+from speech_recognition_amd import ops
+from tests.rnn_helpers import HipBiRNN
+from tests.test_rnn_gpu import make_params
+from tests.tools.bench_sweep import time_fn
+
+B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (64, 499, 1024)))
+ops.set_mixed_precision(True)
+g = torch.Generator().manual_seed(1)
+fwd, bwd = make_params("lstm", 32, H, g, 0.02)
+x = torch.randn(B, T, 32, generator=g, dtype=torch.float64)
+hip = HipBiRNN("lstm", x, None, fwd, bwd, None)
+ws = ops.rnn_sweep_wide_ws(B, H, 2)
+t_w = time_fn(lambda: ops.rnn_sweep_wide_fwd(hip.seq, ws), 5)
+assert not ops.rnn_persist_error(ws) or os.environ.get("ASR_SWEEP_DBG"), "wide sweep timed out"
+t_s = time_fn(lambda: ops.rnn_seq_fwd(hip.seq), 3)
+print(f"B={B} T={T} H={H}: wide sweep {t_w:9.1f} us = {t_w / T:6.2f} us/step    step kernels {t_s:9.1f} us = {t_s / T:6.2f} us/step")
