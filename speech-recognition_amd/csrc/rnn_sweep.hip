@@ -57,6 +57,12 @@ struct SwArgs {
   int spin_limit;
   int dbg;              // timing experiments only (ASR_SWEEP_DBG): 2 no wait, 4 no publish
   int delay;            // s_sleep(2) periods before a gather's first poll
+  // XCD-local placement (speed only): the grid is 1-D, 8 x nx blocks; block b belongs to XCD class b % 8 = group, member b / 8.
+  // Blocks b and b + 8 share an XCD under the round-robin dispatch observed on gfx950 (not promised): the members check it at run
+  // time through `ids` and publish with plain stores (the line stays in the XCD's L2: 0.28 us per hand-off against 0.46-0.69
+  // with write-through stores, tests/tools/micro/pingpong.hip) only if they all sit on one XCD.
+  int xcd, nx, ny, ngroups;
+  float* ids;           // [ngroups][nx][4] (inside the sentinel-filled workspace)
 };
 
 static int g_spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
@@ -72,14 +78,20 @@ template <int CELL, int NQ>
 __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) {
   __shared__ float part[2][4][NQ][16 * 17];
   __shared__ int abort_flag;
-  const SwDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gate_wave = wv < NQ;                       // waves [0, NQ): gate math + publish; waves [NQ, NQ + 4): gather + MFMA
   const int wave = gate_wave ? 0 : wv - NQ;             // K-split index of a gather wave
   const int li = lane & 15, lq = lane >> 4;
-  const int q0 = blockIdx.x * NQ, b0 = blockIdx.y * 16, Q = gridDim.x * NQ;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gx = gridDim.x, gy = gridDim.y;
+  if (a.xcd) {
+    const int g = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (g >= a.ngroups || idx >= a.nx) return;           // (before any barrier: the whole workgroup leaves)
+    bx = idx; by = g % a.ny; bz = g / a.ny; gx = a.nx; gy = a.ny;
+  }
+  const int q0 = bx * NQ, b0 = by * 16, Q = gx * NQ;
   const int B = a.B, T = a.T, H = a.H;
-  const int group = blockIdx.z * gridDim.y + blockIdx.y;
+  const int group = bz * gy + by;
+  const SwDir& d = a.d[bz];
   const long slot_floats = (long)Q * 64;                                  // one slot: [Q][16][4]
   float* xb = a.xbuf + (long)group * SW_SLOTS * slot_floats;
   constexpr int NG = CELL == CELL_LSTM ? 4 : (CELL == CELL_GRU ? 3 : 1);
@@ -115,8 +127,38 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
     if (CELL == CELL_GRU && d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
   }
   const long pub_off = ((long)qn * 16 + bi) * 4;                          // this (slice, row)'s 16 bytes inside a slot
-  if (tid == 0) abort_flag = 0;
+  __shared__ int local_mode;
+  if (tid == 0) { abort_flag = 0; local_mode = 0; }
   __syncthreads();
+  if (a.xcd && wv == 0) {
+    // every member publishes the XCD it runs on; all members read all of them (also a start barrier: the group is resident)
+    const int my = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15) + 1;      // HW_REG_XCC_ID, 1-based
+    float* idp = a.ids + ((long)group * a.nx) * 4;
+    if (lane == 0) {
+      const float f = (float)my;
+      const f32x4 v = {f, f, f, f};
+      float* dst = idp + (long)bx * 4;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    }
+    bool same = true;
+    for (int i0 = 0; i0 < a.nx && same; i0 += 64) {
+      const int i = i0 + lane;
+      const float* src = idp + (long)(i < a.nx ? i : 0) * 4;
+      int spins = 0;
+      for (;;) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+        const bool fresh = __float_as_uint(v.x) != SW_SENT && __float_as_uint(v.w) != SW_SENT;
+        if (__all(fresh)) { same = same && __all(v.x == (float)my); break; }
+        if (++spins > a.spin_limit) { abort_flag = 3; same = false; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (lane == 0) local_mode = same ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const bool local = local_mode != 0 && !(a.dbg & 32);
 
   for (int s = 0; s < T; ++s) {
     const int t = d.reverse ? T - 1 - s : s;
@@ -231,10 +273,16 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
         float* rearm = xb + (long)((s + 2) & (SW_SLOTS - 1)) * slot_floats + pub_off;
         const float sf = __uint_as_float(SW_SENT);
         const f32x4 sent = {sf, sf, sf, sf};
-        asm volatile(
-            "s_waitcnt vmcnt(0)\n\t"                      // retires the re-arming store of the previous step (a step old: no stall)
-            "global_store_dwordx4 %0, %1, off sc1\n\t"
-            "global_store_dwordx4 %2, %3, off sc1" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
+        if (local)                                        // the group sits on one XCD: plain stores keep the line in its L2
+          asm volatile(
+              "s_waitcnt vmcnt(0)\n\t"
+              "global_store_dwordx4 %0, %1, off\n\t"
+              "global_store_dwordx4 %2, %3, off" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
+        else
+          asm volatile(
+              "s_waitcnt vmcnt(0)\n\t"                    // retires the re-arming store of the previous step (a step old: no stall)
+              "global_store_dwordx4 %0, %1, off sc1\n\t"
+              "global_store_dwordx4 %2, %3, off sc1" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
       }
       if (live) {
         const long o = ((long)b * T + t) * H + j;
@@ -291,7 +339,7 @@ static int sw_nq(int B, int H, int ndir) {
 // scratch the caller provides: exchange buffer + 32 words holding the per-launch error word (floats)
 extern "C" long asr_rnn_sweep_ws_floats(int B, int H, int ndir) {
   const long groups = (long)ndir * asr_cdiv(B, 16), Q = asr_cdiv(H, 4);
-  return groups * SW_SLOTS * Q * 64 + 32;
+  return groups * SW_SLOTS * Q * 64 + groups * Q * 4 + 32;       // exchange slots, XCD ids (one piece per workgroup), error words
 }
 
 // 1 when the one-launch sweep can run this layer (otherwise use asr_rnn_seq_fwd)
@@ -325,7 +373,8 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
   const bool lstm = s->rnn_type == CELL_LSTM;
   hipStream_t st = (hipStream_t)stream;
   const long groups = (long)s->ndir * asr_cdiv(B, 16), Q = H / 4;
-  const long xfloats = groups * SW_SLOTS * Q * 64;
+  const long xslots = groups * SW_SLOTS * Q * 64;
+  const long xfloats = xslots + groups * Q * 4;           // + one id piece per (possible) workgroup
   SwArgs a{};
   a.B = B; a.T = T; a.H = H; a.KB = H / 16;
   a.mask = s->mask; a.y = s->y; a.y_ld = s->y_ld;
@@ -356,6 +405,14 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
   }
   const int nq = sw_nq(B, H, s->ndir);
   dim3 grid((unsigned)(Q / nq), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
+  static const int xcd_env = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
+  // one group per XCD: at most 8 groups, and a group's workgroups must fit the 32 compute units of one XCD two at a time
+  const long cap_all = nq == 1 ? sw_fwd_capacity<1>(s->rnn_type) : sw_fwd_capacity<2>(s->rnn_type);
+  if (xcd_env && groups <= 8 && cap_all > 0 && (Q / nq) * 4 <= (cap_all / 8) * 3) {
+    a.xcd = 1; a.nx = (int)(Q / nq); a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
+    a.ids = ws + xslots;
+    grid = dim3((unsigned)(8 * a.nx), 1, 1);
+  }
   if (nq == 1) sw_launch<1>(s->rnn_type, grid, st, a);
   else sw_launch<2>(s->rnn_type, grid, st, a);
   ASR_LAUNCH_CHECK();
