@@ -65,7 +65,9 @@ struct SwArgs {
   float* ids;           // [ngroups][nx][4] (inside the sentinel-filled workspace)
 };
 
-static int g_spin_limit = 1 << 18;   // ~0.3 s of polling: a live hand-off takes microseconds, start-up skew at most milliseconds
+static int g_spin_limit = 1 << 20;   // ~1.2 s of polling.  A live hand-off takes microseconds, but whole-launch stalls of 30-60 ms were seen
+                                     // about once per thousand launches on a shared host (and one of 0.3 s in ~10^5): the limit is a deadlock
+                                     // detector, not a latency bound
 extern "C" void asr_rnn_sweep_set_spin_limit(int polls) { g_spin_limit = polls; }
 extern "C" int asr_rnn_sweep_spin_limit(void) { return g_spin_limit; }
 
@@ -328,11 +330,19 @@ static long sw_fwd_capacity(int rnn_type) {
   return cache[rnn_type];
 }
 
+static bool sw_xcd_enabled() {
+  static const int v = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
+  return v != 0;
+}
+
 static int sw_nq(int B, int H, int ndir) {
   // slices per workgroup: 1 (one workgroup per 4 units, shortest matrix phase) unless that grid would not fit the chip
   static const int forced = getenv("ASR_SWEEP_NQ") ? atoi(getenv("ASR_SWEEP_NQ")) : 0;
   if ((forced == 1 || forced == 2) && (H / 4) % forced == 0) return forced;
   const long wgs = (long)(H / 4) * asr_cdiv(B, 16) * ndir;
+  // XCD-local placement wants a group on the 32 compute units of one XCD, one workgroup each (measured on the las_small layer:
+  // 64 single-slice workgroups per XCD 2.05 us per step, 32 two-slice ones 1.83; without the placement 1.99 / 2.08)
+  if (sw_xcd_enabled() && (long)ndir * asr_cdiv(B, 16) <= 8 && H / 4 > 32 && H / 8 <= 32 && (H / 4) % 2 == 0) return 2;
   return wgs <= 256 ? 1 : 2;
 }
 
@@ -405,13 +415,14 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
   }
   const int nq = sw_nq(B, H, s->ndir);
   dim3 grid((unsigned)(Q / nq), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
-  static const int xcd_env = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
+  const bool xcd_env = sw_xcd_enabled();
   // one group per XCD: at most 8 groups, and a group's workgroups must fit the 32 compute units of one XCD two at a time
   const long cap_all = nq == 1 ? sw_fwd_capacity<1>(s->rnn_type) : sw_fwd_capacity<2>(s->rnn_type);
   if (xcd_env && groups <= 8 && cap_all > 0 && (Q / nq) * 4 <= (cap_all / 8) * 3) {
     a.xcd = 1; a.nx = (int)(Q / nq); a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
     a.ids = ws + xslots;
     grid = dim3((unsigned)(8 * a.nx), 1, 1);
+    if (!getenv("ASR_SWEEP_DELAY")) a.delay = 9;           // hand-offs inside an XCD are shorter (measured optimum 9-10 x 128 cycles)
   }
   if (nq == 1) sw_launch<1>(s->rnn_type, grid, st, a);
   else sw_launch<2>(s->rnn_type, grid, st, a);

@@ -208,7 +208,7 @@ def test_sweep_timeout_raises_the_error_words_and_drains():
         torch.cuda.synchronize()
         assert ops.rnn_persist_error(ws) and float(flag[0]) == 1.0
     finally:
-        ops.rnn_sweep_set_spin_limit(1 << 18)
+        ops.rnn_sweep_set_spin_limit(1 << 20)
     ops.rnn_seq_fwd_persist(hip.seq, ws, flag)
     torch.cuda.synchronize()
     assert not ops.rnn_persist_error(ws)

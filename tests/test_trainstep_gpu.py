@@ -93,7 +93,7 @@ def test_sweep_timeout_skips_the_update_and_surfaces_later():
             ws = tr.step(*batch, use_teacher_forcing=True)
         tr.synchronize()
     finally:
-        ops.rnn_sweep_set_spin_limit(1 << 18)
+        ops.rnn_sweep_set_spin_limit(1 << 20)
     assert torch.equal(model.store.flat, before) and torch.equal(model.store.adam_m, m_before), "an invalid step must not update anything"
     assert int(model.state[0]) == it_before and int(model.state[2]) == 1
     ws = tr.step(*batch, use_teacher_forcing=True)       # a good step: trains again, the error stays on record
@@ -111,7 +111,7 @@ def test_sweep_timeout_skips_the_update_and_surfaces_later():
             ws2 = tr2.step(*batch, use_teacher_forcing=True)
         tr2.synchronize()
     finally:
-        ops.rnn_sweep_set_spin_limit(1 << 18)
+        ops.rnn_sweep_set_spin_limit(1 << 20)
     assert torch.equal(model2.store.flat, init) and int(model2.state[0]) == 0 and int(model2.state[2]) == 1
     with pytest.raises(RuntimeError, match="hand-off timed out"):
         tr2.read_stats(ws2)
