@@ -69,6 +69,8 @@ struct SbArgs {
   int spin_limit;
   int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish
   int delay;                    // s_sleep(2) periods before a gather's first poll
+  int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
+  float* ids;                   // [ngroups][nx][4]
 };
 
 // abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
@@ -94,21 +96,57 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   __shared__ __attribute__((aligned(16))) float part[2][4][NT][256];   // partial dh blocks of the gather waves (MFMA C layout), by step parity
   __shared__ int abort_flag;
   __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
-  const SbDir& d = a.d[blockIdx.z];
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gy = gridDim.y;
+  if (a.xcd) {
+    const int g = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (g >= a.ngroups || idx >= a.nx) return;                     // (before any barrier: the whole workgroup leaves)
+    bx = idx; by = g % a.ny; bz = g / a.ny; gy = a.ny;
+  }
+  const SbDir& d = a.d[bz];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
   const int li = lane & 15, lq = lane >> 4;
-  const int G = a.G, gi_ = blockIdx.x / G, gj_ = blockIdx.x % G;    // (i, j): ds of unit group i, partial dh of unit group j
-  const int b0 = blockIdx.y * 16;
+  const int G = a.G, gi_ = bx / G, gj_ = bx % G;    // (i, j): ds of unit group i, partial dh of unit group j
+  const int b0 = by * 16;
   const int B = a.B, T = a.T, H = a.H;
-  const int group = blockIdx.z * gridDim.y + blockIdx.y;
+  const int group = bz * gy + by;
   const long blk = (long)NT * 256;                                  // floats per block
   const long slot_floats = (long)G * G * blk;
   float* xb = a.xbuf + (long)group * SB_SLOTS * slot_floats;
   const int lds_limit = a.spin_limit > (1 << 20) ? a.spin_limit : (a.spin_limit << 4);   // LDS polls are ~16x shorter than fabric polls
-  if (tid == 0) abort_flag = 0;
+  __shared__ int local_mode;
+  if (tid == 0) { abort_flag = 0; local_mode = 0; }
   if (tid < 4) g_done[tid] = 0;
   __syncthreads();
+  if (a.xcd && wv == 4) {
+    // every member publishes the XCD it runs on; all members read all of them (also a start barrier: the group is resident)
+    const int my = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15) + 1;      // HW_REG_XCC_ID, 1-based
+    float* idp = a.ids + ((long)group * a.nx) * 4;
+    if (lane == 0) {
+      const float f = (float)my;
+      const f32x4 v = {f, f, f, f};
+      float* dst = idp + (long)bx * 4;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    }
+    bool same = true;
+    for (int i0 = 0; i0 < a.nx && same; i0 += 64) {
+      const int i = i0 + lane;
+      const float* src = idp + (long)(i < a.nx ? i : 0) * 4;
+      int spins = 0;
+      for (;;) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+        const bool fresh = __float_as_uint(v.x) != SB_SENT && __float_as_uint(v.w) != SB_SENT;
+        if (__all(fresh)) { same = same && __all(v.x == (float)my); break; }
+        if (++spins > a.spin_limit) { abort_flag = 5; same = false; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    if (lane == 0) local_mode = same ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const bool local = local_mode != 0 && !(a.dbg & 32);
 
   if (gather_wave) {
     // ------------------------------------------------------------------------------------------ GATHER + GATE GRADIENTS + PRODUCT
@@ -365,8 +403,13 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
-      if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
-      if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
+      if (local) {                                                   // the group sits on one XCD: plain stores keep the lines in its L2
+        if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 0);
+        if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 0);
+      } else {
+        if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
+        if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
+      }
     }
   }
   __syncthreads();
@@ -402,7 +445,7 @@ extern "C" long asr_rnn_sweep_bwd_ws_floats(int B, int H, int ndir) {
   int nt = 1, G = 1;
   if (!sb_geometry(B, H, ndir, &nt, &G)) return 32;
   const long groups = (long)ndir * asr_cdiv(B, 16);
-  return groups * SB_SLOTS * G * G * nt * 256 + 32;
+  return groups * SB_SLOTS * G * G * nt * 256 + groups * G * G * 4 + 32;   // exchange slots, XCD ids (one piece per workgroup), error words
 }
 
 template <int NT>
@@ -449,7 +492,8 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   int nt = 1, G = 1;
   sb_geometry(B, H, s->ndir, &nt, &G);
   const long groups = (long)s->ndir * asr_cdiv(B, 16);
-  const long xfloats = groups * SB_SLOTS * G * G * nt * 256;
+  const long xslots = groups * SB_SLOTS * G * G * nt * 256;
+  const long xfloats = xslots + groups * G * G * 4;
   ASR_CHECK(xfloats * 4 < 2147483647L, ASR_ERR_SHAPE, "asr_rnn_sweep_bwd: exchange buffer beyond 2 GB");
   SbArgs a{};
   a.B = B; a.T = T; a.H = H; a.G = G; a.mask = s->mask; a.dy = gs->dy; a.dy_ld = gs->dy_ld;
@@ -479,6 +523,13 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
     ASR_LAUNCH_CHECK();
   }
   dim3 grid((unsigned)(G * G), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
+  static const int xcd_env = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
+  const long cap_all = nt == 1 ? sb_capacity<1>(s->rnn_type) : sb_capacity<2>(s->rnn_type);
+  if (xcd_env && groups <= 8 && cap_all > 0 && (long)G * G * 4 <= (cap_all / 8) * 3) {
+    a.xcd = 1; a.nx = G * G; a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
+    a.ids = ws + xslots;
+    grid = dim3((unsigned)(8 * a.nx), 1, 1);
+  }
   if (nt == 1) sb_launch<1>(s->rnn_type, grid, st, a);
   else sb_launch<2>(s->rnn_type, grid, st, a);
   ASR_LAUNCH_CHECK();
