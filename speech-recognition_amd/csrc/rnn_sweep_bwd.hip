@@ -424,6 +424,13 @@ static bool sb_geometry(int B, int H, int ndir, int* nt, int* G) {
   if (H <= 0 || H % 16 != 0 || H > 256) return false;
   const long groups = (long)ndir * asr_cdiv(B, 16);
   static const int forced = getenv("ASR_SWEEP_BWD_NT") ? atoi(getenv("ASR_SWEEP_BWD_NT")) : 0;
+  static const int xcd_env = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
+  // XCD-local placement (one group per XCD) wants the square on the 32 compute units of one XCD, one workgroup each: take the
+  // larger unit group when that makes it fit (DeepSpeech2 layer, H = 128: 8 x 8 workgroups 2.9 us per step, 4 x 4 2.35)
+  if (!forced && xcd_env && groups <= 8 && H % 32 == 0 && (H / 16) * (H / 16) > 32 && (H / 32) * (H / 32) <= 32) {
+    *nt = 2; *G = H / 32;
+    return true;
+  }
   for (int t = 1; t <= 2; ++t) {
     if (H % (16 * t) != 0) continue;
     if (forced && forced != t && H % (16 * forced) == 0) continue;
