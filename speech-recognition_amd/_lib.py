@@ -232,6 +232,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C speech-recognition_amd/csrc`). speech_recognition_amd has no CPU fallback.")
+    # PyTorch first: it ships its own HIP runtime (libamdhip64) and hands us its streams and allocations, so that copy must be
+    # the one this process binds - loading the library before torch would pull in the system runtime instead, and every launch
+    # then fails with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
