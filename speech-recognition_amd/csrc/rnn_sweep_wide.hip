@@ -159,7 +159,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
             if (spins > a.spin_limit) { abort_flag = 1 | (s << 8); ok2 = false; break; }
             __builtin_amdgcn_s_sleep(4);
           }
-          if (!ok2) break;
+          if (!ok2) goto wave_sync;                      // (never leave the step loop in front of the workgroup barrier)
         }
         bool done = false;
         // addresses: wave-uniform slot base in SGPRs + one 32-bit byte offset per k-step; the batch tile is the instruction's
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
           if (spins > a.spin_limit) { abort_flag = 2 | (s << 8); break; }
           __builtin_amdgcn_s_sleep(2);
         }
-        if (!done) break;
+        if (!done) goto wave_sync;
       }
       float(*ptw)[4][2][16 * 17] = part[s & 1];
 #pragma unroll
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
         }
       }
     }
+  wave_sync:
     float(*pt)[4][2][16 * 17] = part[s & 1];
     __syncthreads();
     if (abort_flag) break;

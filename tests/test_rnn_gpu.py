@@ -287,3 +287,30 @@ def test_wide_sweep_equals_wide_step_kernels_mixed_precision(B, T, H, masked, in
             assert_close(outs[0][k], ref, 1e-3, k)
     finally:
         ops.set_mixed_precision(False)
+
+
+def test_wide_sweep_timeout_sets_the_error_word_and_drains():
+    """spin limit 0 on the wide sweep: the gather waves give up at once, every wave of every workgroup must still reach the
+    workgroup barrier of the step and leave (no hang), the error word and the sticky flag are set; the next launch is clean."""
+    from speech_recognition_amd import ops
+    ops.set_mixed_precision(True)
+    try:
+        B, T, H = 20, 6, 512
+        g = torch.Generator().manual_seed(9)
+        fwd, bwd = make_params("lstm", 8, H, g, 0.05)
+        x = torch.randn(B, T, 8, generator=g, dtype=torch.float64)
+        hip = HipBiRNN("lstm", x, None, fwd, bwd, None)
+        ws = ops.rnn_sweep_wide_ws(B, H, 2)
+        flag = torch.zeros(1, device="cuda")
+        ops.rnn_sweep_set_spin_limit(0)
+        try:
+            ops.rnn_sweep_wide_fwd(hip.seq, ws, flag)
+            torch.cuda.synchronize()
+            assert ops.rnn_persist_error(ws) and float(flag[0]) == 1.0
+        finally:
+            ops.rnn_sweep_set_spin_limit(1 << 20)
+        ops.rnn_sweep_wide_fwd(hip.seq, ws, flag)
+        torch.cuda.synchronize()
+        assert not ops.rnn_persist_error(ws)
+    finally:
+        ops.set_mixed_precision(False)
