@@ -161,6 +161,10 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
   }
   __syncthreads();
   const bool local = local_mode != 0 && !(a.dbg & 32);
+  if (a.xcd && tid == 0) {                             // diagnosis: err[2] = workgroups that publish XCD-locally, err[3] = all
+    atomicAdd(a.err + 2, local ? 1u : 0u);
+    atomicAdd(a.err + 3, 1u);
+  }
 
   for (int s = 0; s < T; ++s) {
     const int t = d.reverse ? T - 1 - s : s;

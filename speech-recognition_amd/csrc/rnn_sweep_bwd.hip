@@ -147,6 +147,10 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   }
   __syncthreads();
   const bool local = local_mode != 0 && !(a.dbg & 32);
+  if (a.xcd && tid == 0) {                             // diagnosis: err[2] = workgroups that publish XCD-locally, err[3] = all
+    atomicAdd(a.err + 2, local ? 1u : 0u);
+    atomicAdd(a.err + 3, 1u);
+  }
 
   if (gather_wave) {
     // ------------------------------------------------------------------------------------------ GATHER + GATE GRADIENTS + PRODUCT

@@ -77,8 +77,9 @@ def main():
             t_b = time_fn(bwd_once, args.iters) - time_fn(copy_only, args.iters)
             assert not ops.rnn_persist_error(pws), "backward hand-off timed out"
             results[sweep] = (y, [dd["saved"].clone() for dd in hip.dirs], [gd["dh0"].clone() for gd in gds])
+            loc = lambda w: tuple(int(v) for v in w[-32:].view(torch.int32)[2:4].tolist())     # (XCD-local workgroups, all)
             print(f"{name} {rt} B={B} T={T} H={H} sweep={int(sweep)}: fwd {t_f:8.1f} us = {t_f / T:5.2f} us/step   "
-                  f"bwd {t_b:8.1f} us = {t_b / T:5.2f} us/step", flush=True)
+                  f"bwd {t_b:8.1f} us = {t_b / T:5.2f} us/step   XCD-local workgroups fwd {loc(ws)} bwd {loc(pws)}", flush=True)
         if len(results) == 2:
             ya, sa, ha = results[True]
             yb, sb, hb = results[False]
