@@ -37,7 +37,7 @@ WORKLOADS = {
     # tally at the fabric although the Infinity Cache serves it
     # algorithmic_bytes: activations kept for backward written once + read once (2 x 0.9 GB), logits 131 MB x 5 touches,
     # Adam 28 B x 16 M parameters, features 51 MB, every weight matrix read twice (forward product, input gradient)
-    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=2 * 7.02e9 + 4.16e9, algorithmic_bytes=3.1e9,
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=2 * 6.17e9 + 3.74e9, algorithmic_bytes=3.1e9,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
