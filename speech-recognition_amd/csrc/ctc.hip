@@ -19,6 +19,13 @@ __device__ __forceinline__ float logaddexp_(float a, float b) {
   if (m <= CTC_NEG) return CTC_NEG;
   return m + log1pf(expf(-fabsf(a - b)));
 }
+// log(e^a + e^b + e^c) for the lattice recursions: one max, three hardware exponentials, one hardware logarithm (the two nested
+// logaddexp calls cost two expf + two log1pf per state and step on the dependent chain).  Absolute error ~1e-7 in the log domain.
+__device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  if (m <= CTC_NEG) return CTC_NEG;
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
 __device__ __forceinline__ int ctc_label_len(const int32_t* lab, int L, int pad) {
   int n = 0;
   for (int i = 0; i < L; ++i) n += (lab[i] != pad) ? 1 : 0;  // measure.py:36 count_nonzero(y != pad)
@@ -52,6 +59,11 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* logits, long
   }
 }
 
+// Barrier for the rolling LDS rows of the lattice: orders LDS only.  __syncthreads() also waits for every outstanding global
+// store (the alpha / gamma rows written each step) to be acknowledged - a global-memory round trip on each of the 2 T dependent
+// steps; nothing in the lattice needs those stores before the kernel ends, except alpha[t][s], which the SAME thread reads back.
+__device__ __forceinline__ void ctc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* lp, float* alpha, float* gamma, const int32_t* labels, int T, int L,
                                                           int pad, float* per_sample, float* stats, float inv_batch) {
   extern __shared__ float sh[];  // two rolling rows of S
@@ -71,27 +83,35 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* lp, float
     r0[s] = v;
     al[s] = v;
   }
-  __syncthreads();
+  ctc_lds_barrier();
+  // The emission log-probabilities of the NEXT frame are loaded before the barrier of the current one: the barrier orders memory, so
+  // a load placed after it would add a global-memory round trip to each of the T dependent steps (measured 1.4 us per step)
+  const bool one_pass = S <= 256;                         // one state per thread: the prefetch registers below cover the row
+  // whether state tid may be entered from tid - 2 / left towards tid + 2 (distinct neighbouring labels): constant over time
+  const bool skip_a = tid < Sb && tid >= 2 && (tid & 1) && lab[tid >> 1] != lab[(tid >> 1) - 1];
+  const bool skip_b = tid + 2 < Sb && (tid & 1) && lab[(tid >> 1) + 1] != lab[tid >> 1];
+  float lp_nx = (one_pass && tid < S && T > 1) ? lpb[(long)S + tid] : 0.f;
   for (int t = 1; t < T; ++t) {
     const float* prev = (t & 1) ? r0 : r1;
     float* cur = (t & 1) ? r1 : r0;
+    const float lp_t = lp_nx;
+    if (one_pass && tid < S && t + 1 < T) lp_nx = lpb[(long)(t + 1) * S + tid];
     for (int s = tid; s < S; s += 256) {
       float v = CTC_NEG;
       if (s < Sb) {
-        v = prev[s];
-        if (s >= 1) v = logaddexp_(v, prev[s - 1]);
-        if (s >= 2 && (s & 1) && lab[s >> 1] != lab[(s >> 1) - 1]) v = logaddexp_(v, prev[s - 2]);
-        v = v <= CTC_NEG ? CTC_NEG : v + lpb[(long)t * S + s];
+        const bool skip = one_pass ? skip_a : (s >= 2 && (s & 1) && lab[s >> 1] != lab[(s >> 1) - 1]);
+        v = ctc_lse3(prev[s], s >= 1 ? prev[s - 1] : CTC_NEG, skip ? prev[s - 2] : CTC_NEG);
+        v = v <= CTC_NEG ? CTC_NEG : v + (one_pass ? lp_t : lpb[(long)t * S + s]);
       }
       cur[s] = v;
       al[(long)t * S + s] = v;
     }
-    __syncthreads();
+    ctc_lds_barrier();
   }
   const float* last = ((T - 1) & 1) ? r1 : r0;
   float ll = last[Sb - 1];
   if (Sb >= 2) ll = logaddexp_(ll, last[Sb - 2]);
-  __syncthreads();
+  ctc_lds_barrier();
   if (tid == 0) {
     const float per = -ll / (float)len;   // measure.py:41 divides by the label length, unguarded like the reference
     per_sample[b] = per;
@@ -104,23 +124,37 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* lp, float
     const float a = al[(long)(T - 1) * S + s];
     ga[(long)(T - 1) * S + s] = (a > CTC_NEG && v > CTC_NEG) ? expf(a + v - ll) : 0.f;
   }
-  __syncthreads();
+  ctc_lds_barrier();
+  // same here: the three emission values and alpha of the next iteration are in registers before the barrier
+  float b0n = 0.f, b1n = 0.f, b2n = 0.f, an = 0.f;
+  auto bload = [&](int t) {
+    const float* lpn = lpb + (long)(t + 1) * S;
+    b0n = lpn[tid];
+    b1n = tid + 1 < S ? lpn[tid + 1] : 0.f;
+    b2n = tid + 2 < S ? lpn[tid + 2] : 0.f;
+    an = al[(long)t * S + tid];
+  };
+  if (one_pass && tid < S && T >= 2) bload(T - 2);
   for (int t = T - 2, k = 0; t >= 0; --t, ++k) {
     const float* nxt = (k & 1) ? r1 : r0;
     float* cur = (k & 1) ? r0 : r1;
     const float* lpn = lpb + (long)(t + 1) * S;
+    const float c0 = b0n, c1 = b1n, c2 = b2n, ca = an;
+    if (one_pass && tid < S && t >= 1) bload(t - 1);
     for (int s = tid; s < S; s += 256) {
       float v = CTC_NEG;
       if (s < Sb) {
-        v = nxt[s] <= CTC_NEG ? CTC_NEG : nxt[s] + lpn[s];
-        if (s + 1 < Sb && nxt[s + 1] > CTC_NEG) v = logaddexp_(v, nxt[s + 1] + lpn[s + 1]);
-        if (s + 2 < Sb && (s & 1) && lab[(s >> 1) + 1] != lab[s >> 1] && nxt[s + 2] > CTC_NEG) v = logaddexp_(v, nxt[s + 2] + lpn[s + 2]);
+        const bool skip = one_pass ? skip_b : (s + 2 < Sb && (s & 1) && lab[(s >> 1) + 1] != lab[s >> 1]);
+        const float t0 = nxt[s] <= CTC_NEG ? CTC_NEG : nxt[s] + (one_pass ? c0 : lpn[s]);
+        const float t1 = (s + 1 < Sb && nxt[s + 1] > CTC_NEG) ? nxt[s + 1] + (one_pass ? c1 : lpn[s + 1]) : CTC_NEG;
+        const float t2 = (skip && nxt[s + 2] > CTC_NEG) ? nxt[s + 2] + (one_pass ? c2 : lpn[s + 2]) : CTC_NEG;
+        v = ctc_lse3(t0, t1, t2);
       }
       cur[s] = v;
-      const float a = al[(long)t * S + s];
+      const float a = one_pass ? ca : al[(long)t * S + s];
       ga[(long)t * S + s] = (a > CTC_NEG && v > CTC_NEG) ? expf(a + v - ll) : 0.f;
     }
-    __syncthreads();
+    ctc_lds_barrier();
   }
 }
 
