@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
       for (int r = 0; r < 4; ++r) ptw[wave][n][(lq * 4 + r) * 17 + li] = acc[n][r];
     }
     float(*pt)[NQ][16 * 17] = part[s & 1];
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait for the gate waves' output stores of the previous step to be acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (abort_flag) break;
 
     if (gate_wave) {

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
     }
   wave_sync:
     float(*pt)[4][2][16 * 17] = part[s & 1];
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait for the gate waves' output stores of the previous step to be acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (abort_flag) break;
 
     if (gate_wave) {
