@@ -49,16 +49,11 @@ struct DbArgs {
 __device__ __forceinline__ bool db_gather9(const float* base, const unsigned (&off)[9], const bool (&use)[9], f32x4 (&v)[9], volatile int* abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000) {
-    int first = 8;
-#pragma unroll
-    for (int i = 8; i >= 0; --i)
-      if (__any(use[i])) first = i;
-    unsigned po = off[0];
-    bool pu = use[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i)
-      if (i == first) { po = off[i]; pu = use[i]; }
-    if (!ds_probe(base, po, pu, abort_flag, limit, code)) return false;
+    // the probe piece is chosen with wave-uniform branches over STATIC indices (a run-time pick from the offset array goes
+    // through scratch memory: a memory round trip in front of every gather)
+    if (__any(use[0])) { if (!ds_probe(base, off[0], use[0], abort_flag, limit, code)) return false; }
+    else if (__any(use[4])) { if (!ds_probe(base, off[4], use[4], abort_flag, limit, code)) return false; }
+    else if (__any(use[8])) { if (!ds_probe(base, off[8], use[8], abort_flag, limit, code)) return false; }
   }
   for (int spins = 0;; ++spins) {
     asm volatile(
@@ -89,6 +84,36 @@ __device__ __forceinline__ bool db_gather9(const float* base, const unsigned (&o
       *abort_flag = code | (__shfl(bad, fl, 64) << 16) | (fl << 20);
       return false;
     }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// the five-piece gather of decoder_sweep_common.h with the static probe choice
+__device__ __forceinline__ bool db_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], volatile int* abort_flag,
+                                           int limit, int delay, int code) {
+  if (delay >= 0 && delay < 1000) {
+    if (__any(use[0])) { if (!ds_probe(base, off[0], use[0], abort_flag, limit, code)) return false; }
+    else if (__any(use[4])) { if (!ds_probe(base, off[4], use[4], abort_flag, limit, code)) return false; }
+  }
+  for (int spins = 0;; ++spins) {
+    asm volatile(
+        "s_nop 4\n\t"
+        "global_load_dwordx4 %0, %5, %10 sc1\n\t"
+        "global_load_dwordx4 %1, %6, %10 sc1\n\t"
+        "global_load_dwordx4 %2, %7, %10 sc1\n\t"
+        "global_load_dwordx4 %3, %8, %10 sc1\n\t"
+        "global_load_dwordx4 %4, %9, %10 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+        : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "s"(base)
+        : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (use[i]) ok = ok && ds_fresh(v[i]);
+    if (__all(ok) || delay < 0) return true;
+    if (*abort_flag) return false;
+    if (spins > limit) { *abort_flag = code; return false; }
     __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -270,7 +295,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
             }
             use[4] = true;
             off[4] = (unsigned)((a.o_c1 + (long)(tile * G + gi) * blkf + (long)pos * 4) * 4);
-            if (!ds_gather5(base, off, use, v, abort_flag, a.spin_limit, a.delay, 2 | (p << 8))) break;
+            if (!db_gather5(base, off, use, v, abort_flag, a.spin_limit, a.delay, 2 | (p << 8))) break;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
               if (use[m]) accP += v[m];
@@ -348,7 +373,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
             off[m] = use[m] ? (unsigned)((rowb + (long)snd * D + 4 * fq) * 4) : 0u;
           }
           use[4] = false; off[4] = 0u;
-          if (!ds_gather5(base, off, use, v, abort_flag, a.spin_limit, a.delay, 3 | (p << 8))) break;
+          if (!db_gather5(base, off, use, v, abort_flag, a.spin_limit, a.delay, 3 | (p << 8))) break;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int m = 0; m < 4; ++m)
