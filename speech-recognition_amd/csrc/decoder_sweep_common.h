@@ -48,16 +48,13 @@ __device__ __forceinline__ bool ds_probe(const float* base, unsigned off, bool u
 __device__ __forceinline__ bool ds_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], volatile int* abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000) {
-    int first = 4;
-#pragma unroll
-    for (int i = 4; i >= 0; --i)
-      if (__any(use[i])) first = i;
-    unsigned po = off[0];
-    bool pu = use[0];
-#pragma unroll
-    for (int i = 1; i < 5; ++i)
-      if (i == first) { po = off[i]; pu = use[i]; }
-    if (!ds_probe(base, po, pu, abort_flag, limit, code)) return false;
+    // the probe piece is the first one any lane uses - chosen with wave-uniform branches over STATIC indices (a run-time pick
+    // from the offset array goes through scratch memory: a memory round trip in front of every gather)
+    if (__any(use[0])) { if (!ds_probe(base, off[0], use[0], abort_flag, limit, code)) return false; }
+    else if (__any(use[1])) { if (!ds_probe(base, off[1], use[1], abort_flag, limit, code)) return false; }
+    else if (__any(use[2])) { if (!ds_probe(base, off[2], use[2], abort_flag, limit, code)) return false; }
+    else if (__any(use[3])) { if (!ds_probe(base, off[3], use[3], abort_flag, limit, code)) return false; }
+    else if (__any(use[4])) { if (!ds_probe(base, off[4], use[4], abort_flag, limit, code)) return false; }
   }
   for (int spins = 0;; ++spins) {
     asm volatile(
