@@ -49,8 +49,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* A, int M, int 
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s = 0.f;
-  if (c < N)
-    for (int r = r0 + w; r < r1; r += 4) s += A[(long)r * lda + c];
+  if (c < N) {
+    // eight rows in flight per thread: the loop is a chain of dependent-looking loads otherwise (one memory round trip per row:
+    // 14.6 us for a [2688 x 384] bias gradient that is 4 MB of data)
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int r = r0 + w;
+    for (; r + 28 < r1; r += 32) {
+      const float* q = A + (long)r * lda + c;
+      const float v0 = q[0], v1 = q[4 * lda], v2 = q[8 * lda], v3 = q[12 * lda], v4 = q[16 * lda], v5 = q[20 * lda], v6 = q[24 * lda], v7 = q[28 * lda];
+      p0 += v0 + v4; p1 += v1 + v5; p2 += v2 + v6; p3 += v3 + v7;
+    }
+    for (; r < r1; r += 4) p0 += A[(long)r * lda + c];
+    s = (p0 + p1) + (p2 + p3);
+  }
   red[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -73,8 +84,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, int M, in
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = r0 + w; r < r1; r += 4) { const double v = x[(long)r * ld + c]; s += v; q += v * v; }
+  if (c < C) {
+    int r = r0 + w;
+    for (; r + 12 < r1; r += 16) {                        // four rows in flight per thread
+      const float* p = x + (long)r * ld + c;
+      const double v0 = p[0], v1 = p[4 * ld], v2 = p[8 * ld], v3 = p[12 * ld];
+      s += (v0 + v1) + (v2 + v3);
+      q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+    for (; r < r1; r += 4) { const double v = x[(long)r * ld + c]; s += v; q += v * v; }
+  }
   red[0][w][l] = s; red[1][w][l] = q;
   __syncthreads();
   if (w == 0 && c < C) {
