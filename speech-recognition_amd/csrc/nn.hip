@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* A, int M, int 
 }
 extern "C" int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream) {
   ASR_CHECK(A && out && M > 0 && N > 0 && lda >= N, ASR_ERR_ARG, "asr_colsum: bad argument");
-  const int rpb = 128;
+  const int rpb = 128;                                    // (32 rows per block: 26 us - the atomics of four times as many blocks cost more than the shorter chains save)
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)asr_cdiv(N, 64), (unsigned)asr_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, A, M, N,
                      lda, out, rpb);
   ASR_LAUNCH_CHECK();
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
   double s = 0.0, q = 0.0;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c];
+#pragma unroll 4                                          // (the rows' loads in flight together: the loop is latency bound otherwise)
     for (int r = r0 + w; r < r1; r += 4) {
       float d = dy[(long)r * lddy + c];
       if (relu && !(y[(long)r * ldy + c] > 0.f)) d = 0.f;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
   }
   const int rows_per_block = (M + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+#pragma unroll 4
   for (int r = r0 + w; r < r1; r += 4) {
     float d = dy[(long)r * lddy + c];
     if (relu && !(y[(long)r * ldy + c] > 0.f)) d = 0.f;
