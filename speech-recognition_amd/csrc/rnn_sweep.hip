@@ -65,9 +65,9 @@ struct SwArgs {
   float* ids;           // [ngroups][nx][4] (inside the sentinel-filled workspace)
 };
 
-static int g_spin_limit = 1 << 20;   // ~1.2 s of polling.  A live hand-off takes microseconds, but whole-launch stalls of 30-60 ms were seen
-                                     // about once per thousand launches on a shared host (and one of 0.3 s in ~10^5): the limit is a deadlock
-                                     // detector, not a latency bound
+static int g_spin_limit = 1 << 20;   // ~1.2 s of polling: a deadlock detector, not a latency bound.  A live hand-off takes microseconds (16 000
+                                     // individually timed launches: none over 1.2x the median, tests/tools/stall_hunt.py); one unexplained
+                                     // time-out at the earlier limit of 0.3 s was seen in ~10^5 launches on a shared host
 extern "C" void asr_rnn_sweep_set_spin_limit(int polls) { g_spin_limit = polls; }
 extern "C" int asr_rnn_sweep_spin_limit(void) { return g_spin_limit; }
 
