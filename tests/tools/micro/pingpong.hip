@@ -11,15 +11,17 @@ __device__ __forceinline__ void put(float* p, f32x4 v) {
   if (STORE_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
+template <int LOAD_PLAIN>
 __device__ __forceinline__ f32x4 get(const float* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  if (LOAD_PLAIN) asm volatile("buffer_inv sc1\n\tglobal_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 
 // block 0 = ping, block `peer` = pong; each round: ping writes slot a (value i), pong waits for it and writes slot b, ping waits.
 // Every lane of wave 0 moves its own 16 bytes (a 1 KB message per direction), like one piece of the sweeps' hand-offs.
-template <int STORE_SC1>
+template <int STORE_SC1, int LOAD_PLAIN>
 __global__ void __launch_bounds__(64) pingpong(float* buf, int peer, int rounds, int* xcc, long long* cycles) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (lane == 0) xcc[b] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID bits [3:0]
@@ -33,10 +35,10 @@ __global__ void __launch_bounds__(64) pingpong(float* buf, int peer, int rounds,
     if (b == 0) {
       put<STORE_SC1>(a, (f32x4){tag, tag, tag, tag});
       int spins = 0;
-      for (;;) { f32x4 v = get(c); if (__all(v.x == tag && v.w == tag) || (dead = ++spins > (1 << 16))) break; }
+      for (;;) { f32x4 v = get<LOAD_PLAIN>(c); if (__all(v.x == tag && v.w == tag) || (dead = ++spins > (1 << 16))) break; }
     } else {
       int spins = 0;
-      for (;;) { f32x4 v = get(a); if (__all(v.x == tag && v.w == tag) || (dead = ++spins > (1 << 16))) break; }
+      for (;;) { f32x4 v = get<LOAD_PLAIN>(a); if (__all(v.x == tag && v.w == tag) || (dead = ++spins > (1 << 16))) break; }
       put<STORE_SC1>(c, (f32x4){tag, tag, tag, tag});
     }
   }
@@ -48,19 +50,20 @@ int main() {
   hipMalloc(&buf, 1 << 16); hipMalloc(&xcc, 4096); hipMalloc(&cyc, 8);
   const int rounds = 2000, grid = 64;
   int hx[64];
-  for (int sc1 = 1; sc1 >= 0; --sc1)
+  for (int mode = 0; mode < 3; ++mode)
     for (int peer : {8, 16, 1, 4}) {
+      const int sc1 = mode != 1, lp = mode == 2;
       for (int rep = 0; rep < 2; ++rep) {
         hipMemset(buf, 0, 1 << 16);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        if (sc1) pingpong<1><<<grid, 64>>>(buf, peer, rounds, xcc, cyc); else pingpong<0><<<grid, 64>>>(buf, peer, rounds, xcc, cyc);
+        if (mode == 0) pingpong<1, 0><<<grid, 64>>>(buf, peer, rounds, xcc, cyc); else if (mode == 1) pingpong<0, 0><<<grid, 64>>>(buf, peer, rounds, xcc, cyc); else pingpong<1, 1><<<grid, 64>>>(buf, peer, rounds, xcc, cyc);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(hx, xcc, sizeof(hx), hipMemcpyDeviceToHost);
         long long hc; hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
-        if (rep && hc < 0) printf("store %-5s peer %2d  xcc %d/%d: TIMED OUT (stale read)\n", sc1 ? "sc1" : "plain", peer, hx[0], hx[peer]);
-        else if (rep) printf("store %-5s peer %2d  xcc(ping)=%d xcc(pong)=%d  %.0f ns per one-way hand-off (1 KB message)\n", sc1 ? "sc1" : "plain", peer, hx[0], hx[peer],
+        if (rep && hc < 0) printf("store %-5s load %-9s peer %2d  xcc %d/%d: TIMED OUT (stale read)\n", sc1 ? "sc1" : "plain", lp ? "inv+plain" : "sc1", peer, hx[0], hx[peer]);
+        else if (rep) printf("store %-5s load %-9s peer %2d  xcc(ping)=%d xcc(pong)=%d  %.0f ns per one-way hand-off (1 KB message)\n", sc1 ? "sc1" : "plain", lp ? "inv+plain" : "sc1", peer, hx[0], hx[peer],
                         ms * 1e6 / rounds / 2);
       }
     }
