@@ -513,9 +513,10 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
-  // see rnn_sweep.hip; the owner math sits between a gather and the next publish here, so less of the round is dead time
-  // (las_small: 4.04 us per step with no delay, 3.13 with 8 x 128 cycles, 3.33 with 12)
-  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 6;
+  // see rnn_sweep.hip.  Here the next step's operand loads already sit between a step's product and the next gather's first poll, so
+  // no extra delay pays inside the training step (las_small ms per step with 0 / 2 / 4 / 6 / 8 x 128 cycles: 11.87 / 11.92 / 11.99 /
+  // 12.03 / 12.10; alone, with nothing else on the device, 6-8 measured best)
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 0;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d)", d);
