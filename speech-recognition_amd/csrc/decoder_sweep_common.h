@@ -3,6 +3,9 @@
 #pragma once
 #include "common.h"
 
+#ifndef DS_PROBE_SLEEP
+#define DS_PROBE_SLEEP 4            // 64-cycle periods between two polls of the probe piece
+#endif
 #define DS_SLOTS 4
 #define DS_SENT 0x7FC0DEADu
 #define DS_NC 8                    // time chunks per batch row
@@ -41,7 +44,7 @@ __device__ __forceinline__ bool ds_probe(const float* base, unsigned off, bool u
     if (__all(ok)) return true;
     if (*abort_flag) return false;
     if (spins > limit) { *abort_flag = code; return false; }
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(DS_PROBE_SLEEP);
   }
 }
 // up to 5 self-validating 16-byte pieces per lane: re-read until none of the USED ones holds the sentinel
