@@ -212,16 +212,14 @@ def _sweep_entries(trainer, model, buf, layer, rt, B, T2, H, peak):
                                PEAK_F32_MFMA, bound="latency (reported against mfma)", us_per_dependent_step=round(t * 1e6 / T2, 2)))
     if "persist_bwd_ws" in buf:
         dirs = buf["dirs"]
-        snap = [dd["saved"].clone() for dd in dirs]               # the backward sweep overwrites the saved gates with ds
         dy = torch.randn(B, T2, 2 * H, device="cuda") * 1e-3
         zeros = [torch.zeros(B, H, device="cuda") for _ in range(2)]
         dcs = [torch.zeros(B, H, device="cuda") for _ in range(2)]
         gds = [dict(dh_last=None, dc=dcs[d] if rt == "lstm" else None, dy_carry=dd["dy_carry"] if buf["mask"] is not None else None,
-                    direct=dd["direct"], dh0=dd["dh0"]) for d, dd in enumerate(dirs)]
+                    direct=dd["direct"], dh0=dd["dh0"], ds=dd["ds"]) for d, dd in enumerate(dirs)]
 
-        def restore():
-            for dd, sv, dc in zip(dirs, snap, dcs):
-                dd["saved"].copy_(sv)
+        def restore():                                            # (the sweep leaves the saved activations alone: ds goes to its own buffer)
+            for dd, dc in zip(dirs, dcs):
                 dc.copy_(zeros[0])
                 if buf["mask"] is not None:
                     ops.fill(dd["dy_carry"], 0.0)
@@ -365,6 +363,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sweep_errors = []      # what the sweeps recorded about every time-out of this run (goes into the JSON line: a retry is never silent)
+
     def measure():
         trainer, model = build_trainer(wl, strategy, use_graph=not args.no_graph)
         for _ in range(max(args.warmup, 3)):      # >= 3: eager warm-up, graph capture, first replay
@@ -381,15 +381,9 @@ def main():
         failed = 0.0
         try:
             stats = trainer.read_stats(ws)
-        except RuntimeError as e:                  # a persistent-kernel hand-off timed out on this rank
+        except RuntimeError as e:                  # a hand-off of a one-launch sweep timed out on this rank: keep the evidence
             print(f"[bench] rank {rank}: {e}", file=sys.stderr)
-            for i, lw in enumerate(getattr(ws, "layers", [])):      # which sweep gave up, and where (code | step << 8)
-                for k in ("persist_ws", "persist_bwd_ws"):
-                    if k in lw["rnn"] and _ops.rnn_persist_error(lw["rnn"][k]):
-                        w = _ops.rnn_persist_error(lw["rnn"][k])
-                        print(f"[bench]   layer {i} {k}: error word {w:#x} (code {w & 255}, step {w >> 8})", file=sys.stderr)
-            if getattr(ws, "dsweep_ws", None) is not None and _ops.decoder_sweep_error(ws.dsweep_ws):
-                print(f"[bench]   decoder sweep: error word {_ops.decoder_sweep_error(ws.dsweep_ws):#x}", file=sys.stderr)
+            sweep_errors.append({"rank": rank, "attempt": len(sweep_errors) + 1, "reports": getattr(e, "reports", [])})
             stats, failed = [float("nan")] * 3, 1.0
         if world > 1:
             import torch.distributed as dist
@@ -432,7 +426,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
         "config": {"workload": wl["text"] + "; " + PRECISION_TEXT[precision], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
                    "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "persistent_rnn": bool(_layers.PERSISTENT_RNN), "remeasured": retried,
-                   "final_loss": round(loss, 4)},
+                   "sweep_errors": sweep_errors, "overlap": bool(_layers.Overlap.enabled), "final_loss": round(loss, 4)},
         "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": wl.get("traffic") if precision == "f32" else None,
                      "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"},

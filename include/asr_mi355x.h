@@ -348,8 +348,11 @@ typedef struct asr_rnn_seq_grad {
   float* dy_carry[2];                       /* [B,H] scratch, zeroed by the caller (masked runs)     */
   float* direct[2];                         /* scratch [B,H] per direction (zeroed by the call)      */
   float* dh0[2]; long dh0_ld[2];            /* out: gradient wrt initial h or NULL                   */
+  float* ds[2];                             /* asr_rnn_sweep_bwd only: out, the gate-sum gradients [B,T,NS*H], a buffer of its own */
 } asr_rnn_seq_grad;
-/* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs. */
+/* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs (written in place over the
+ * activations, one time step per launch).  asr_rnn_sweep_bwd writes them to g->ds[d] instead: its resident workgroups read the
+ * saved activations of a step from several compute units at their own pace, so it must not overwrite them. */
 int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* stream);
 /* The same layer forward / backward-through-time as ONE launch each (rnn_sweep.hip / rnn_sweep_bwd.hip): workgroups stay
  * resident over all T steps, keep their slice of the recurrent kernel in registers and hand the recurrent quantity to each
@@ -361,7 +364,7 @@ int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* strea
  * T >= 2 and the grid fits the chip (asr_rnn_sweep[_bwd]_supported); every spin is bounded.  ws: asr_rnn_sweep[_bwd]_ws_floats() floats, re-armed by every call; the uint32 at
  * ws[ws_floats - 32] is non-zero after the call if a hand-off timed out (results invalid); err_flag: optional device float
  * that is set to 1.0f in that case and never cleared by the library (TrainStep's sticky error cell).
- * asr_rnn_sweep_set_spin_limit: polls before a hand-off gives up (default 2^18, about 0.3 s; tests force time-outs with 0). */
+ * asr_rnn_sweep_set_spin_limit: polls before a hand-off gives up (default 2^20, about 1.2 s: a deadlock detector, not a latency bound; tests force time-outs with 0). */
 long asr_rnn_sweep_ws_floats(int B, int H, int ndir);
 int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, void* stream);
@@ -370,6 +373,17 @@ int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
 int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, float* err_flag, void* stream);
 void asr_rnn_sweep_set_spin_limit(int polls);
 int asr_rnn_sweep_spin_limit(void);
+/* Every sweep keeps 32 diagnosis words behind its exchange buffer (the last 32 floats of an asr_rnn_sweep[_bwd|_wide]_ws_floats()
+ * workspace; 288 floats from the end of a decoder-sweep workspace; csrc/sweep_common.h): word 0 the error word, word 4 the
+ * workgroups that have started, word 5 the workgroups expected, words 8-15 what the first workgroup that gave up saw (its
+ * abort word, block, XCD, arrivals at that moment, publish mode, wave, clock).  "arrivals < expected" in that record means a
+ * workgroup was never resident (another tenant held its compute unit); equal means a hand-off was lost with everybody there.
+ * asr_sweep_gate: one wave on `stream` that returns once the sweep owning `diag_words` has all its workgroups resident, or after
+ * max_microseconds: launched in front of side-stream work that is to run BESIDE that sweep (the weight-gradient GEMMs of the
+ * previous layer next to a BPTT sweep - the overlap of north_star's "all-reduce ... overlapped with the backward RNN sweep"
+ * applied to the step's own off-critical-path products), so that it cannot take the sweep's compute units first.  No
+ * reference counterpart (TensorFlow schedules its own streams). */
+int asr_sweep_gate(const float* diag_words, int max_microseconds, void* stream);
 
 /* Wide layers under mixed precision (las_large: H = 1024, B = 64): one launch per layer with the recurrent kernel resident as
  * bf16 MFMA operands (64 KB per workgroup, one workgroup of 8 hidden units per compute unit and direction), h_t exchanged as bf16

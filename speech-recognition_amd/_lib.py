@@ -98,7 +98,7 @@ class DecoderSweepGrad(C.Structure):
 class RnnSeqGrad(C.Structure):
     _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
                 ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("direct", c_f32p * 2), ("dh0", c_f32p * 2),
-                ("dh0_ld", c_long * 2)]
+                ("dh0_ld", c_long * 2), ("ds", c_f32p * 2)]
 
 
 class ConvDesc(C.Structure):
@@ -159,6 +159,7 @@ SIGNATURES = {
     "asr_rnn_sweep_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P, _P, _P]),
     "asr_rnn_sweep_set_spin_limit": (None, [C.c_int]),
     "asr_rnn_sweep_spin_limit": (C.c_int, []),
+    "asr_sweep_gate": (C.c_int, [_P, C.c_int, _P]),
     "asr_rnn_sweep_wide_supported": (C.c_int, [C.c_int] * 5),
     "asr_rnn_sweep_wide_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
     "asr_rnn_sweep_wide_fwd": (C.c_int, [C.POINTER(RnnSeq), _P, _P, _P]),

@@ -46,6 +46,7 @@ struct DsArgs {
   unsigned* err; float* err_flag;
   int spin_limit, delay;
   int dbg;                                  // timing experiments only (ASR_DECODER_SWEEP_DBG): 2 = gathers do not wait
+  int prio;                                 // s_setprio level of every wave
 };
 
 __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   volatile int* cC = flags + 1;
   volatile int *cE = flags + 4, *cA = flags + 8, *cB = flags + 12, *cD = flags + 16;   // scores, partial, slices gathered, sums
   if (tid < 20) flags[tid] = 0;
+  if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)
+  swd_setprio(a.prio);
 
   // ---- resident operands ----
   if (attn) {
@@ -480,8 +483,10 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
     // err[1]: 0x7fffffff - the EARLIEST (step, stage) that gave up anywhere; err[2]: the workgroup that reported it last
     __hip_atomic_fetch_max(a.err + 1, 0x7fffffffu - (unsigned)(((*abort_flag >> 8) << 8) | (*abort_flag & 255)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a.err[32 + w] = (unsigned)*abort_flag;               // per-workgroup record (diagnosis: tests/tools/dbg_decoder_sweep.py)
+    swd_record(a.err, (unsigned)*abort_flag, 0);
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) swd_depart(a.err);
 }
 
 static size_t ds_lds_bytes(int Hd, int D) {
@@ -538,11 +543,12 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
   a.err = reinterpret_cast<unsigned*>(ws + xfloats);
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
+  a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_DELAY")) : 8;   // negative: timing experiment, gathers do not wait
   {
     const size_t n = (size_t)xfloats;
     hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st,
-                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 32);
+                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
     (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
     ASR_LAUNCH_CHECK();
   }

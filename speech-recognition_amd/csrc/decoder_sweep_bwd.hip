@@ -42,7 +42,7 @@ struct DbArgs {
   float* xbuf; long xbytes;
   long o_p1, o_c1, o_p0, o_c0, o_pc, o_q, slot_floats;
   unsigned* err; float* err_flag;
-  int spin_limit, delay, dbg;
+  int spin_limit, delay, dbg, prio;
 };
 
 // up to 9 self-validating pieces per lane (layer 1: 4 partial-dH pieces, 4 dq pieces, 1 dc piece)
@@ -165,6 +165,8 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
   volatile int* abort_flag = flags;
   volatile int *cG = flags + 4, *cO = flags + 8, *cS = flags + 12, *cA1 = flags + 16, *cA2 = flags + 20, *cA3 = flags + 24, *cA4 = flags + 28;
   if (tid < 64) flags[tid] = 0;
+  if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)
+  swd_setprio(a.prio);
 
   // ---- resident attention operands ----
   if (attn) {
@@ -595,8 +597,10 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
     __hip_atomic_store(a.err, (unsigned)*abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_max(a.err + 1, 0x7fffffffu - (unsigned)(((*abort_flag >> 8) << 8) | (*abort_flag & 255)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a.err[32 + w] = (unsigned)*abort_flag;
+    swd_record(a.err, (unsigned)*abort_flag, 0);
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) swd_depart(a.err);
 }
 
 static bool db_geometry(int Hd, int D, int* nt, int* G) {
@@ -677,11 +681,12 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
   a.err = reinterpret_cast<unsigned*>(ws + xfloats);
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
+  a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_BWD_DELAY")) : 4;
   {
     const size_t n = (size_t)xfloats;
     hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
-                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 32);
+                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
     (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
     ASR_LAUNCH_CHECK();
   }

@@ -1,7 +1,7 @@
 // Shared pieces of the one-launch decoder sweeps (decoder_sweep.hip forward, decoder_sweep_bwd.hip backward): the sentinel
 // hand-off primitives (self-validating 16-byte pieces, bounded polls) and the LDS progress words.  See rnn_sweep.hip for the protocol.
 #pragma once
-#include "common.h"
+#include "sweep_common.h"
 
 #ifndef DS_PROBE_SLEEP
 #define DS_PROBE_SLEEP 4            // 64-cycle periods between two polls of the probe piece
@@ -12,10 +12,6 @@
 #define DS_MAXTC 32                // encoder frames per chunk
 #define DS_MAXHB 4                 // K blocks of h per gather wave: Hd <= 256
 #define DS_MAXCB 8                 // K blocks of the context per gather wave: D <= 512
-
-extern "C" int asr_rnn_sweep_spin_limit(void);
-long asr_sweep_capacity(const void* kernel, int threads);
-__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

@@ -87,7 +87,15 @@ static void launch_t(const GemmPlan& g, const AL& al, const BL& bl) {
   if (forced == 3) { launch_cfg<AL, BL, TA, TB, 64, 128, 2, 2>(g, al, bl); return; }
   if (forced == 4) { launch_cfg<AL, BL, TA, TB, 64, 64, 2, 2>(g, al, bl); return; }
   // (a 256 x 128 tile for the bf16 path spills: 72-93 TF against 314-414 TF with 128 x 128 on the las_large shapes)
-  const double s128 = score(128, 128, 1.0), s12864 = score(128, 64, 0.92), s64128 = score(64, 128, 0.92), s64 = score(64, 64, 0.80);
+  // per-tile efficiency: the bigger tile stages less per flop, but its fixed cost per tile (first loads, the C write of all
+  // co-resident tiles at once: ~7 K-iterations' worth at 128 x 128 against ~3 at 64 x 64, tests/tools/gemm_k_sweep.py) only
+  // amortises over a long K loop.  With <= 32 K-iterations per workgroup (every product of the las_small / deepspeech steps:
+  // K or K / split_k <= 1024) the small tile wins inside the training step (las_small: 4.4 -> 4.1 ms of GEMMs)
+  const int sk1 = d->split_k > 1 ? d->split_k : 1;
+  const int k_iters = asr_cdiv(asr_cdiv(d->K, sk1), GEMM_BK);
+  static const double e64s = getenv("ASR_GEMM_E64") ? atof(getenv("ASR_GEMM_E64")) : 1.02;
+  const double e64 = k_iters <= 32 ? e64s : 0.80, e128x64 = k_iters <= 32 ? 0.97 : 0.92;
+  const double s128 = score(128, 128, 1.0), s12864 = score(128, 64, e128x64), s64128 = score(64, 128, e128x64), s64 = score(64, 64, e64);
   if (s128 >= s12864 && s128 >= s64128 && s128 >= s64) launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl);
   else if (s12864 >= s64128 && s12864 >= s64) launch_cfg<AL, BL, TA, TB, 128, 64, 2, 2>(g, al, bl);
   else if (s64128 >= s64) launch_cfg<AL, BL, TA, TB, 64, 128, 2, 2>(g, al, bl);

@@ -31,7 +31,7 @@
 // fit per CU, so a grid of <= 256 is co-resident even when another stream (RCCL) occupies part of the chip.
 #include <stdlib.h>
 
-#include "common.h"
+#include "sweep_common.h"
 
 #define CELL_LSTM 0
 #define CELL_GRU 1
@@ -63,17 +63,43 @@ struct SwArgs {
   // with write-through stores, tests/tools/micro/pingpong.hip) only if they all sit on one XCD.
   int xcd, nx, ny, ngroups;
   float* ids;           // [ngroups][nx][4] (inside the sentinel-filled workspace)
+  int prio;             // s_setprio level of every wave
 };
 
 static int g_spin_limit = 1 << 20;   // ~1.2 s of polling: a deadlock detector, not a latency bound.  A live hand-off takes microseconds (16 000
                                      // individually timed launches: none over 1.2x the median, tests/tools/stall_hunt.py); one unexplained
                                      // time-out at the earlier limit of 0.3 s was seen in ~10^5 launches on a shared host
 extern "C" void asr_rnn_sweep_set_spin_limit(int polls) { g_spin_limit = polls; }
+int asr_sweep_prio(void) {
+  static const int v = getenv("ASR_SWEEP_PRIO") ? atoi(getenv("ASR_SWEEP_PRIO")) : 3;
+  return v;
+}
 extern "C" int asr_rnn_sweep_spin_limit(void) { return g_spin_limit; }
 
-__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero) {
+__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero, uint32_t expected) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero_words[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero_words[threadIdx.x] = (int)threadIdx.x == SWD_EXPECTED ? expected : 0u;
+}
+
+// One wave that waits (bounded by the 100 MHz s_memrealtime clock) until a sweep has counted all of its workgroups in: put in
+// front of side-stream work that is meant to run BESIDE that sweep, so that the sweep is resident before the other work can
+// take compute units (sweep_common.h).  A pure scheduling hint: when the time is up the stream simply goes on.
+__global__ void sweep_gate_kernel(const unsigned* diag, unsigned long long max_ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned arrived = __hip_atomic_load(diag + SWD_ARRIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned expected = __hip_atomic_load(diag + SWD_EXPECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (expected != 0u && arrived >= expected) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+extern "C" int asr_sweep_gate(const float* diag_words, int max_microseconds, void* stream) {
+  ASR_CHECK(diag_words && max_microseconds >= 0, ASR_ERR_ARG, "asr_sweep_gate: bad argument");
+  hipLaunchKernelGGL(sweep_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const unsigned*>(diag_words),
+                     (unsigned long long)max_microseconds * 100ull);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
 }
 
 template <int CELL, int NQ>
@@ -90,6 +116,8 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
     if (g >= a.ngroups || idx >= a.nx) return;           // (before any barrier: the whole workgroup leaves)
     bx = idx; by = g % a.ny; bz = g / a.ny; gx = a.nx; gy = a.ny;
   }
+  if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)
+  swd_setprio(a.prio);
   const int q0 = bx * NQ, b0 = by * 16, Q = gx * NQ;
   const int B = a.B, T = a.T, H = a.H;
   const int group = bz * gy + by;
@@ -219,7 +247,8 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
             ok = ok && __float_as_uint(av[i].x) != SW_SENT && __float_as_uint(av[i].y) != SW_SENT && __float_as_uint(av[i].z) != SW_SENT &&
                  __float_as_uint(av[i].w) != SW_SENT;
         if (__all(ok) || (a.dbg & 2)) break;
-        if (++spins > a.spin_limit || *(volatile int*)&abort_flag) { abort_flag = 1; break; }
+        if (*(volatile int*)&abort_flag) break;
+        if (++spins > a.spin_limit) { abort_flag = 1 | (s << 8); break; }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
@@ -307,9 +336,11 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
     }
   }
   if (abort_flag && tid == 0) {
-    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    swd_record(a.err, (unsigned)abort_flag, local ? 1 : 0);
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) swd_depart(a.err);
 }
 
 // Workgroups of `kernel` the chip can hold at once (occupancy API x compute units), or -1 when no device is visible (the CPU-only
@@ -398,6 +429,7 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
   a.err_flag = err_flag;
   a.spin_limit = g_spin_limit;
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
+  a.prio = asr_sweep_prio();
   // the first poll of a gather cannot succeed before the publish of the step has crossed the fabric (~1 us): polling earlier only
   // adds traffic in front of it (measured on las_small: 2.38 us per step with no delay, 1.98 with 12 x 128 cycles, 2.15 with 16)
   a.delay = getenv("ASR_SWEEP_DELAY") ? atoi(getenv("ASR_SWEEP_DELAY")) : 12;
@@ -410,24 +442,25 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
     p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
   }
-  // every exchange word is re-armed with the sentinel and the error word cleared on every call, by an ordinary kernel
-  // (graph-capturable; see asr_zero_async for why not a memset node)
-  {
-    const size_t n = (size_t)xfloats;
-    const unsigned grid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
-    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SW_SENT, a.err, 32);
-    ASR_LAUNCH_CHECK();
-  }
   const int nq = sw_nq(B, H, s->ndir);
   dim3 grid((unsigned)(Q / nq), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
+  const unsigned expected = (unsigned)((Q / nq) * groups);         // workgroups that take part (XCD mode launches spare ones that leave at once)
   const bool xcd_env = sw_xcd_enabled();
   // one group per XCD: at most 8 groups, and a group's workgroups must fit the 32 compute units of one XCD two at a time
   const long cap_all = nq == 1 ? sw_fwd_capacity<1>(s->rnn_type) : sw_fwd_capacity<2>(s->rnn_type);
-  if (xcd_env && groups <= 8 && cap_all > 0 && (Q / nq) * 4 <= (cap_all / 8) * 3) {
+  if (xcd_env && groups <= 8 && cap_all > 0 && Q / nq <= 32 && (Q / nq) * 4 <= (cap_all / 8) * 3) {
     a.xcd = 1; a.nx = (int)(Q / nq); a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
     a.ids = ws + xslots;
     grid = dim3((unsigned)(8 * a.nx), 1, 1);
     if (!getenv("ASR_SWEEP_DELAY")) a.delay = 9;           // hand-offs inside an XCD are shorter (measured optimum 9-10 x 128 cycles)
+  }
+  // every exchange word is re-armed with the sentinel and the diagnosis words cleared on every call, by an ordinary kernel
+  // (graph-capturable; see asr_zero_async for why not a memset node)
+  {
+    const size_t n = (size_t)xfloats;
+    const unsigned fgrid = (unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3(fgrid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SW_SENT, a.err, 16, expected);
+    ASR_LAUNCH_CHECK();
   }
   if (nq == 1) sw_launch<1>(s->rnn_type, grid, st, a);
   else sw_launch<2>(s->rnn_type, grid, st, a);

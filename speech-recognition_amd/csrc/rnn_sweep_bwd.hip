@@ -15,12 +15,20 @@
 // H/4 separate blocks (measured: 3.9 - 5.0 us per step, bound by the write-through stores).  The square needs neither.
 //
 // Hand-off = the forward sweep's: blocks are self-validating (a SENTINEL NaN pattern marks "not written yet"), written with
-// 16-byte write-through stores, polled with `global_load_dwordx4 ... sc1`; 4 slots, step p publishes into slot (p+1) % 4 and
-// the PUBLISHER re-arms the block it wrote two steps earlier (slot (p-1) % 4): having gathered everybody's step p-1 blocks
-// it knows every workgroup has finished step p-1 and with it the gather of slot (p-1) % 4.  All stores to one word come
-// from one wave in program order, with `s_waitcnt vmcnt(0)` once per step between the sentinel and the next value.  (Do
-// NOT let the reader re-arm: two agents storing to the same word race even when one store is issued only after the other
-// was seen retired - an earlier version of this file did that and lost blocks on small, fast shapes.)
+// 16-byte write-through stores, polled with `global_load_dwordx4 ... sc1`; step p publishes into slot (p+1) % 6, which the
+// gather of step p+1 reads, and the PUBLISHER re-arms its block THREE steps later.  Why three: in the square a workgroup gathers
+// only the G blocks of ITS row - not everybody's, as in the forward sweep's all-gather - so the return of its gather of step p
+// proves only that the G senders of that row have finished their gather of step p-1, and, one hop further back, that EVERY
+// workgroup has finished its gather of step p-2.  The readers of a publisher's block sit in another row: all that is certain
+// about them at publish time p is "gather p-2 done", i.e. the block published at step p-3 has been consumed.  (Rounds 1-2
+// re-armed one step earlier, on the all-gather's argument: a reader that was still polling its gather p-1 for some OTHER, late
+// sender then saw the sentinel come back over a block it had already seen fresh, and waited for ever - the "lost hand-off"
+// time-outs that showed once other kernels shared the memory system with the sweep; sweep_common.h's record caught one: all 256
+// workgroups resident, gather stuck at step 70.)  Six slots: the sentinel stored at step p+3 is retired by the publisher's
+// `s_waitcnt vmcnt(0)` of step p+4, before its publish of step p+4; a reader polls the slot again for step p+7, after it has
+// consumed that publisher's block of step p+5 - so what it finds there is the sentinel or the new block, never the old one.
+// All stores to one word come from one wave in program order.  (Do NOT let the reader re-arm: two agents storing to the same
+// word race even when one store is issued only after the other was seen retired.)
 //
 // Wave roles (512 threads).  gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave with
 // write-through stores in flight cannot consume a later load before their acknowledgements are back:
@@ -34,23 +42,20 @@
 // Every spin is bounded; on time-out the error word (who gave up | step << 8) and the caller's sticky flag are raised.
 #include <stdlib.h>
 
-#include "common.h"
+#include "sweep_common.h"
 
 #define CELL_LSTM 0
 #define CELL_GRU 1
 #define CELL_RNN 2
-#define SB_SLOTS 4
+#define SB_SLOTS 6
 #define SB_SENT 0x7FC0DEADu
-
-extern "C" int asr_rnn_sweep_spin_limit(void);
-long asr_sweep_capacity(const void* kernel, int threads);
-__global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero_words, int nzero);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct SbDir {
   const float* U; long ldu;
-  float* saved;                 // [B,T,NS*H]: activations in, ds out
+  const float* saved;           // [B,T,NS*H]: gate activations of the forward pass
+  float* ds;                    // [B,T,NS*H]: gate-sum gradients out (never the same buffer: see the kernel)
   const float* hseq; const float* cseq;
   const float* h0; long h0_ld; const float* c0; long c0_ld;
   const float* dh_last; long dh_last_ld;
@@ -71,6 +76,9 @@ struct SbArgs {
   int delay;                    // s_sleep(2) periods before a gather's first poll
   int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
   float* ids;                   // [ngroups][nx][4]
+  int prio;                     // s_setprio level of every wave
+  int probe;                    // 1: poll ONE piece per lane until it is fresh before the whole gather goes out (a quarter of the poll traffic:
+                                // for launches that share the memory system with throughput work released beside them)
 };
 
 // abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
@@ -92,7 +100,11 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   constexpr int UW = 4 * NT;                                        // units per gather wave (= its MFMA k-steps: one unit x 4 gate slots each)
   constexpr int LP = 4 / NT;                                        // lanes that share a position (they split the senders)
   constexpr int TRLD = 4 * UW + 4;                                  // padded row of a wave's ds image
-  __shared__ __attribute__((aligned(16))) float tr[4][16][TRLD];    // wave-private: ds of the wave's units, [row][unit * 4 + gate slot]
+  // ds of a gather wave's units, [row][unit * 4 + gate slot]: written and read back (as MFMA A operands) by the gather wave itself,
+  // read once more by the publish waves, which store ds to memory AFTER their publish.  Three copies by step: the gather wave
+  // rewrites copy p % 3 at step p + 3, when its gather has returned - which implies this workgroup's publish of step p + 1, and
+  // the publish waves stored step p's ds before that
+  __shared__ __attribute__((aligned(16))) float tr[3][4][16][TRLD];
   __shared__ __attribute__((aligned(16))) float part[2][4][NT][256];   // partial dh blocks of the gather waves (MFMA C layout), by step parity
   __shared__ int abort_flag;
   __shared__ int g_done[4];                                         // per gather wave: steps whose partial block is in LDS
@@ -102,6 +114,8 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     if (g >= a.ngroups || idx >= a.nx) return;                     // (before any barrier: the whole workgroup leaves)
     bx = idx; by = g % a.ny; bz = g / a.ny; gy = a.ny;
   }
+  if (threadIdx.x == 0) swd_arrive(a.err);                          // start handshake (sweep_common.h)
+  swd_setprio(a.prio);
   const SbDir& d = a.d[bz];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
@@ -211,10 +225,10 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     };
     Operands nxt[NT];
     fetch(0, nxt);
-    // ds of the previous step, written to `saved` one step late: the other workgroups of this row read the same saved
-    // activations, and only when the gather of step p + 1 has returned is it certain that all of them have finished step p
-    float dsp[NT][NS];
-    int t_prev = 0;
+    // ds goes OUT OF PLACE.  The G workgroups of a square's row all read the same saved activations, one step ahead, and a row's
+    // writer has no proof of where its row mates are: its gather returns blocks of column i, i.e. of the workgroups (i', i) - only
+    // one of which is a row mate.  Writing ds over `saved` one step late (the first version of this kernel) therefore raced
+    // with a slow row mate's fetch: seen as garbage gradients once other kernels ran beside the sweep (round 3, tests/tools/dbg_overlap.py).
     for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
       const bool cell = p < T;
       const int step = T - 1 - p;
@@ -232,6 +246,16 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         f32x4 v0, v1, v2, v3;
         int spins = 0;
         for (int w = 0; w < a.delay; ++w) __builtin_amdgcn_s_sleep(2);
+        if (a.probe) {
+          for (;;) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0) : "v"(p0) : "memory");
+            const bool ok = !u0 || (__float_as_uint(v0.x) != SB_SENT && __float_as_uint(v0.w) != SB_SENT);
+            if (__all(ok) || (a.dbg & 2)) break;
+            if (*(volatile int*)&abort_flag) break;
+            if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
+            for (int w = 0; w < a.probe; ++w) __builtin_amdgcn_s_sleep(1);
+          }
+        }
         for (;;) {
           asm volatile(
               "global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -323,18 +347,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           dirv[r] = dir;
         }
       }
-      if (!cell) {
-        if (writer) {                                               // the last step's ds (its gather has returned)
-#pragma unroll
-          for (int r = 0; r < NT; ++r)
-            if (live[r]) {
-              float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
-#pragma unroll
-              for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
-            }
-        }
-        break;
-      }
+      if (!cell) break;
       // the wave's ds image in its own LDS rows, gate slots in the order the recurrent kernel's column blocks take them
       // (GRU: z, r, r (.) d(a_hh); the input-side slot 2 does not multiply U), then read back as MFMA A operands: lane (li, lq) =
       // (row, gate slot) of unit ks - the same wave wrote it, its LDS accesses execute in order
@@ -344,15 +357,15 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         img.x = ds[r][0];
         img.y = CELL == CELL_RNN ? 0.f : ds[r][1];
         img.z = CELL == CELL_LSTM ? ds[r][2] : (CELL == CELL_GRU ? ds[r][3] : 0.f);
-        img.w = CELL == CELL_LSTM ? ds[r][3] : 0.f;
-        *reinterpret_cast<f32x4*>(&tr[wv][4 * plq + pt * NT + r][4 * ul]) = img;
+        img.w = CELL == CELL_LSTM ? ds[r][3] : (CELL == CELL_GRU ? ds[r][2] : 0.f);   // GRU: the input-side slot rides along (k-row 3 of U^T is zero)
+        *reinterpret_cast<f32x4*>(&tr[p % 3][wv][4 * plq + pt * NT + r][4 * ul]) = img;
       }
       f32x4 acc[NT];
 #pragma unroll
       for (int t2 = 0; t2 < NT; ++t2) acc[t2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < UW; ++ks) {
-        const float av = tr[wv][li][4 * ks + lq];
+        const float av = tr[p % 3][wv][li][4 * ks + lq];
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwv[t2][ks], acc[t2], 0, 0, 0);
       }
@@ -360,23 +373,9 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       for (int t2 = 0; t2 < NT; ++t2) *reinterpret_cast<f32x4*>(&part[p & 1][wv][t2][lane * 4]) = acc[t2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) *(volatile int*)&g_done[wv] = p + 1;
-      // off the critical path from here: ds of the PREVIOUS step to `saved` (safe now: this step's gather has returned), then the
-      // operands of the next step
-      if (writer && p > 0 && !(a.dbg & 16)) {
-#pragma unroll
-        for (int r = 0; r < NT; ++r)
-          if (live[r]) {
-            float* o = d.saved + ((long)brow[r] * T + t_prev) * NS * H + j;
-#pragma unroll
-            for (int g = 0; g < NS; ++g) o[(long)g * H] = dsp[r][g];
-          }
-      }
+      // off the critical path from here: the operands of the next step.  (ds goes to memory from the publish waves: in this wave the
+      // stores would sit in front of the next gather's polls in the in-order memory counter - measured +0.76 us per step)
       fetch(p + 1, nxt);
-      t_prev = t;
-#pragma unroll
-      for (int r = 0; r < NT; ++r)
-#pragma unroll
-        for (int g = 0; g < NS; ++g) dsp[r][g] = ds[r][g];
     }
     if (writer && CELL == CELL_LSTM && !abort_flag) {
 #pragma unroll
@@ -389,6 +388,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
+    const bool writer = gj_ == 0 && !(a.dbg & 16);                    // column 0 of the square writes the layer's ds
     for (int p = 0; p < T; ++p) {
       bool ok = true;
       for (int i = 0;; ++i) {
@@ -406,21 +406,37 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
-      const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 1) % SB_SLOTS) * slot_floats + my_blk;
+      const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 2) % SB_SLOTS) * slot_floats + my_blk;   // the block of step p - 3
       if (local) {                                                   // the group sits on one XCD: plain stores keep the lines in its L2
         if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 0);
-        if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 0);
+        if (p >= 3 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 0);
       } else {
         if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
-        if (p >= 2 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
+        if (p >= 3 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
+      }
+      if (writer) {
+        // this step's ds, [B, T, NS * H] row-major: 16-byte pieces (row, gate, 4 units), consecutive lanes on consecutive pieces of a
+        // (row, gate) run; the next step's `s_waitcnt vmcnt(0)` retires them a whole exchange round later
+        constexpr int PPR = NS * 4 * NT;                               // pieces per batch row
+        const int step = T - 1 - p, t = d.reverse ? T - 1 - step : step;
+#pragma unroll
+        for (int q = nt_ * 64 + lane; q < 16 * PPR; q += 64 * NT) {
+          const int row = q / PPR, rem = q % PPR, gate = rem / (4 * NT), u4 = rem % (4 * NT);
+          const int sl = CELL == CELL_GRU ? (gate == 2 ? 3 : (gate == 3 ? 2 : gate)) : gate;   // image slot of this output slot
+          const float* src = &tr[p % 3][u4 / NT][row][16 * (u4 % NT) + sl];
+          const f32x4 v = {src[0], src[4], src[8], src[12]};
+          if (b0 + row < B) *reinterpret_cast<f32x4*>(d.ds + ((long)(b0 + row) * T + t) * NS * H + (long)gate * H + gi_ * KU + 4 * u4) = v;
+        }
       }
     }
   }
   __syncthreads();
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    swd_record(a.err, (unsigned)abort_flag, local ? 1 : 0);
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) swd_depart(a.err);
 }
 
 // geometry: tiles per unit group (1 or 2) and the side G of the workgroup square of one (direction, batch tile) group
@@ -513,6 +529,8 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
+  a.prio = asr_sweep_prio();
+  a.probe = getenv("ASR_SWEEP_BWD_PROBE") ? atoi(getenv("ASR_SWEEP_BWD_PROBE")) : 0;
   // see rnn_sweep.hip.  Here the next step's operand loads already sit between a step's product and the next gather's first poll, so
   // no extra delay pays inside the training step (las_small ms per step with 0 / 2 / 4 / 6 / 8 x 128 cycles: 11.87 / 11.92 / 11.99 /
   // 12.03 / 12.10; alone, with nothing else on the device, 6-8 measured best)
@@ -520,9 +538,10 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(gs->ds[d] && gs->ds[d] != s->saved[d], ASR_ERR_ARG, "asr_rnn_sweep_bwd: g->ds[%d] must be a buffer of its own (the sweep cannot write ds over the saved activations)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
     SbDir& p = a.d[d];
-    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.saved = s->saved[d]; p.hseq = s->hseq[d]; p.cseq = s->cseq[d];
+    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.saved = s->saved[d]; p.ds = gs->ds[d]; p.hseq = s->hseq[d]; p.cseq = s->cseq[d];
     p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
     p.dh_last = gs->dh_last[d]; p.dh_last_ld = gs->dh_last_ld[d];
     p.dc = gs->dc[d]; p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];
@@ -531,13 +550,17 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   {
     const size_t n = (size_t)xfloats;
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SB_SENT, a.err, 32);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, SB_SENT, a.err, 16,
+                       (unsigned)(groups * G * G));
     ASR_LAUNCH_CHECK();
   }
   dim3 grid((unsigned)(G * G), (unsigned)asr_cdiv(B, 16), (unsigned)s->ndir);
   static const int xcd_env = getenv("ASR_SWEEP_XCD") ? atoi(getenv("ASR_SWEEP_XCD")) : 1;
   const long cap_all = nt == 1 ? sb_capacity<1>(s->rnn_type) : sb_capacity<2>(s->rnn_type);
-  if (xcd_env && groups <= 8 && cap_all > 0 && (long)G * G * 4 <= (cap_all / 8) * 3) {
+  // XCD-local placement only with one workgroup per compute unit of the XCD (32): two per CU measured slower than the chip-wide
+  // placement (las_small square of 64: 4.4 against 3.4 us per step) - an explicit bound, not the occupancy answer, which moves with
+  // every change of the kernel's register count
+  if (xcd_env && groups <= 8 && cap_all > 0 && G * G <= 32 && (long)G * G * 4 <= (cap_all / 8) * 3) {
     a.xcd = 1; a.nx = G * G; a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
     a.ids = ws + xslots;
     grid = dim3((unsigned)(8 * a.nx), 1, 1);

@@ -39,7 +39,7 @@ struct WwArgs {
   uint32_t* xbuf; long xbytes;   // [ndir][4 slots][H / 8][64 rows][4 words]
   long slot_words;
   unsigned* err; float* err_flag;
-  int spin_limit, dbg;
+  int spin_limit, dbg, prio;
 };
 
 __device__ __forceinline__ uint32_t ww_pack2(float a, float b) {
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
   const int B = a.B, T = a.T, H = a.H, MT = a.MT;
   const int KB = H / 16;                                // K blocks of the packed f32 image
   uint32_t* xb = a.xbuf + (long)blockIdx.z * DS_SLOTS * a.slot_words;
-  if (tid == 0) abort_flag = 0;
+  if (tid == 0) { abort_flag = 0; swd_arrive(a.err); }   // start handshake (sweep_common.h)
+  swd_setprio(a.prio);
 
   // ---- gather waves: resident B operands, built once from the packed f32 image (asr_rnn_pack) ----
   const int w = gate_wave ? 0 : wv - 2;
@@ -297,8 +298,10 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
   __syncthreads();
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    swd_record(a.err, (unsigned)abort_flag, 0);
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid == 0) swd_depart(a.err);
 }
 
 extern "C" int asr_rnn_sweep_wide_supported(int rnn_type, int B, int T, int H, int ndir) {
@@ -335,6 +338,7 @@ extern "C" int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* er
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
+  a.prio = asr_sweep_prio();
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->pre[d] && s->Wp[d] && s->hseq[d] && s->cseq[d] && s->y, ASR_ERR_ARG, "asr_rnn_sweep_wide_fwd: null buffer (dir %d)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_wide_fwd: recurrent dropout is not supported (use asr_rnn_seq_fwd)");
@@ -347,7 +351,8 @@ extern "C" int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* er
   {
     const size_t n = (size_t)xwords;
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 32);
+    hipLaunchKernelGGL(sw_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16,
+                       (unsigned)((H / 8) * s->ndir));
     ASR_LAUNCH_CHECK();
   }
   dim3 grid((unsigned)(H / 8), 1, (unsigned)s->ndir);

@@ -60,12 +60,80 @@ class SideStream:
             fn()
         self._busy = True
 
+    def fork(self):
+        """An event on the current stream marking 'everything enqueued so far': work given to run_after() starts behind it, NOT
+        behind what the caller enqueues between fork() and run_after() (a sweep the work is meant to run beside)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def run_after(self, ev, fns, gate=None):
+        """Enqueue the callables `fns` on the side stream behind the fork event `ev`; gate: the diagnosis words of a sweep that was
+        launched on the main stream after fork() - the side stream then first waits (asr_sweep_gate, bounded) until that sweep is
+        resident, so that its workgroups cannot be kept off the chip by the work released here."""
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            if gate is not None:
+                ops.sweep_gate(gate)
+            for fn in fns:
+                fn()
+        self._busy = True
+
     def join(self):
         if self.stream is not None and self._busy:
             ev = torch.cuda.Event()
             ev.record(self.stream)
             torch.cuda.current_stream().wait_event(ev)
             self._busy = False
+
+
+class Overlap:
+    """Off-critical-path work of the backward pass (weight and bias gradients: nothing downstream in the step reads them before
+    Adam) held back and released BESIDE the next one-launch sweep, behind a gate that lets the sweep become resident first
+    (SideStream.run_after / asr_sweep_gate).  The sweeps are bound by the latency of their dependent hand-offs and keep the matrix
+    pipes ~5 % busy; the dW / dU / db products are throughput work (las_small: ~1.9 ms of them in an 11.8 ms step).
+    MEASURED (round 3, MI355X) AND OFF BY DEFAULT: side by side both lose.  One 105-us GEMM beside the las_small BPTT sweep takes
+    141 us and the sweep 968 instead of 882 us - the sweep advances at ~40 % of its speed while the GEMM's waves share its compute
+    units (tests/tools/bench_beside.py); whole step 11.8 -> 13.2 ms (wave priority 0 / 3, probe polling, 64 x 64 tiles: the same).
+    A latency-bound chain wants the chip to itself; ASR_OVERLAP=1 keeps the experiment runnable.  What the experiment did find: two
+    races of the BPTT sweep that only other kernels' interference exposed (rnn_sweep_bwd.hip: ds out of place, re-arm three steps late)."""
+
+    enabled = os.environ.get("ASR_OVERLAP", "0") == "1"
+
+    def __init__(self, site="overlap"):
+        self.side = SideStream(site, default_on=Overlap.enabled)
+        self.pending = []
+
+    @property
+    def on(self):
+        return self.side.on
+
+    def defer(self, fn):
+        if self.side.on:
+            self.pending.append(fn)
+        else:
+            fn()
+
+    def beside(self, launch, gate):
+        """Run `launch()` (a sweep) on the current stream and release the pending work next to it."""
+        if not self.pending:
+            launch()
+            return
+        ev = self.side.fork()
+        launch()
+        work, self.pending = self.pending, []
+        self.side.run_after(ev, work, gate)
+
+    def flush(self, join=True):
+        """Release what is still pending behind everything enqueued so far (no sweep to hide behind) and, with join, make the
+        current stream wait for the side stream: the end of a backward pass / of a gradient bucket's segment."""
+        if self.pending:
+            work, self.pending = self.pending, []
+            self.side.run_after(self.side.fork(), work, None)
+        if join:
+            self.side.join()
 
 
 def auto_split_k(M, N, K):
@@ -234,33 +302,43 @@ class BiRNN:
             ops.rnn_seq_fwd(buf["seq"])
         return buf["y"]
 
-    def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False, side=None):
+    def backward(self, buf, dy3d, dfinal_h, dc_bufs, dx3d, dx_accumulate=False, side=None, overlap=None):
         """dy3d [B,T,2H]; dfinal_h: per direction gradient wrt the final h state ([B,H] or None);
         dc_bufs: per direction [B,H] buffer holding the gradient wrt the final c state on entry and
         the gradient wrt the initial c state on exit (LSTM).  Returns per-direction dh0 buffers.
         Parameter gradients are accumulated into the store; dx3d (+)= input gradient if not None.
         side: a SideStream - the weight gradients (which read only this layer's own buffers) then run on it,
-        beside whatever the caller enqueues next; the caller join()s it."""
+        beside whatever the caller enqueues next; the caller join()s it.
+        overlap: an Overlap - the work it holds (the previous layer's weight gradients) is released beside THIS layer's
+        backward sweep, and this layer's weight gradients are handed to it for the next sweep; the caller flush()es it."""
         B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
+        pws = None
+        if PERSISTENT_RNN and not buf["rdrop"] and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
+            if "persist_bwd_ws" not in buf:
+                buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
+                for dd in buf["dirs"]:                   # the sweep writes the gate-sum gradients out of place
+                    dd["ds"] = torch.empty_like(dd["saved"])
+            pws = buf["persist_bwd_ws"]
         gds = []
         for d, dd in enumerate(buf["dirs"]):
             if buf["mask"] is not None:
                 ops.fill(dd["dy_carry"], 0.0)
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
-                            dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"]))
-        pws = None
-        if PERSISTENT_RNN and not buf["rdrop"] and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
-            if "persist_bwd_ws" not in buf:
-                buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
-            pws = buf["persist_bwd_ws"]
-        ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
+                            dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"],
+                            ds=dd["ds"] if pws is not None else None))
+        dskey = "ds" if pws is not None else "saved"     # where this backward pass leaves the gate-sum gradients
+        sweep = lambda: ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
+        if overlap is not None:
+            overlap.beside(sweep, ops.sweep_diag_words(pws) if pws is not None else None)
+        else:
+            sweep()
         x2d = buf["x3d"].reshape(B * T, self.Din)
         g, p = self.store.g, self.store.p
 
         def param_grads():      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
             for d, dd in enumerate(buf["dirs"]):
                 nm = self.names[d]
-                ds3 = dd["saved"]
+                ds3 = dd[dskey]
                 ds2 = ds3.view(B * T, -1)
                 mt = dd["mtab"] if buf["drop"] else None
                 cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
@@ -281,13 +359,15 @@ class BiRNN:
                         t0 = T - 1 if dd["reverse"] else 0
                         ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs0)
 
-        if side is not None:
+        if overlap is not None:
+            overlap.defer(param_grads)
+        elif side is not None:
             side.run(param_grads)
         else:
             param_grads()
         if dx3d is not None:
             for d, dd in enumerate(buf["dirs"]):
                 mt = dd["mtab"] if buf["drop"] else None
-                cell_input_grad(rt, H, dd["saved"].view(B * T, -1), p[self.names[d] + "kernel"], dx3d.view(B * T, self.Din),
+                cell_input_grad(rt, H, dd[dskey].view(B * T, -1), p[self.names[d] + "kernel"], dx3d.view(B * T, self.Din),
                                 accumulate=(dx_accumulate or d == 1), c_scale=mt, c_rpg=T)
         return [dd["dh0"] for dd in buf["dirs"]]

@@ -18,7 +18,7 @@ import torch
 
 from .. import ops
 from .. import rng as R
-from ..layers import NG, BiRNN, SideStream, dense_bwd
+from ..layers import NG, BiRNN, Overlap, SideStream, dense_bwd
 from ..measure import CTCLoss
 from ..params import ParamStore, init_value
 from .las import get_rnn_cls
@@ -62,7 +62,8 @@ class DeepSpeech2(ModelProto):
         self.mask_mode = mask_mode
         self.device, self.init_seed = device, seed
         self._ws = {}
-        self._side = SideStream("ds2", default_on=True)
+        self._ov = Overlap("ds2")            # (opt-in experiment) weight gradients released beside the next layer's backward sweep
+        self._side = SideStream("ds2", default_on=True)   # weight gradients on a second stream as soon as a layer's sweep has finished
         self._version, self._packed_version = 0, -1
         self.state = torch.tensor([0, (seed or 0) & 0x7FFFFFFF, 0, 0], dtype=torch.int32, device=device)
 
@@ -238,6 +239,14 @@ class DeepSpeech2(ModelProto):
             segs.append(lambda i=i: self.backward_layer(ws, audio, i))
         return segs
 
+    def bucket_schedule(self):
+        """Per backward segment, the gradient buckets complete when it ends: a recurrent layer's weight gradients run beside the
+        next layer's sweep (layers.Overlap), one segment late; the last two buckets complete together."""
+        n = self.Lr + 1
+        if not self._ov.on or n < 3:
+            return [[k] for k in range(n)]
+        return [[0], []] + [[k - 1] for k in range(2, n - 1)] + [[n - 2, n - 1]]
+
     def backward_ws(self, ws, audio):
         for seg in self.backward_segments(ws, audio):
             seg()
@@ -265,11 +274,15 @@ class DeepSpeech2(ModelProto):
         ops.bn_bwd(y2, None, da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dy.view(B * T2, 2 * H), g[bn + "gamma"], g[bn + "beta"],
                    ws.bn_ws, relu=False)
         dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * H)
-        ws.dfin_next = l.backward(lw["rnn"], ws.dy, ws.dfin_next, ws.dc, dx, side=self._side)   # weight gradients beside the next layer's sweep
-        if getattr(self, "bucket_sync", False) and i > 0:
-            self._side.join()              # data parallel: this layer's gradients form a bucket, complete when the segment ends
+        if self._ov.on:
+            ws.dfin_next = l.backward(lw["rnn"], ws.dy, ws.dfin_next, ws.dc, dx, overlap=self._ov)   # weight gradients beside the next layer's sweep
+        else:
+            ws.dfin_next = l.backward(lw["rnn"], ws.dy, ws.dfin_next, ws.dc, dx, side=self._side)    # weight gradients beside this layer's dX / the next BatchNorm
         if i > 0:
+            if getattr(self, "bucket_sync", False):
+                (self._ov.side if self._ov.on else self._side).join()   # data parallel: a complete bucket when the segment ends
             return
+        self._ov.flush(join=False)         # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
         dy = ws.dx0.view(ws.conv[-1].shape)
         for k in range(len(ws.conv) - 1, -1, -1):
@@ -279,6 +292,7 @@ class DeepSpeech2(ModelProto):
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]
+        self._ov.side.join()
         self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API

@@ -24,7 +24,7 @@ import torch
 
 from .. import _lib, ops
 from .. import rng as R
-from ..layers import NG, NS, BiRNN, SideStream, cell_input_grad, cell_param_grads, dense_bwd
+from ..layers import NG, NS, BiRNN, Overlap, cell_input_grad, cell_param_grads, dense_bwd
 from ..measure import SparseCategoricalAccuracy, SparseCategoricalCrossentropy
 from ..params import ParamStore, init_value
 from .model_proto import ModelProto
@@ -121,7 +121,7 @@ class LAS(ModelProto):
         self.listener = Listener(self)
         self.attend_and_speller = AttendAndSpeller(self)
         self._ws = {}
-        self._side, self._side_dec = SideStream("enc"), SideStream("dec")
+        self._ov = Overlap("las")            # weight gradients released beside the next backward sweep (layers.Overlap)
         self._packed_version = -1
         self._version = 0
         # device state: [0] optimizer iterations, [1] dropout seed (advanced by the trainer each step)
@@ -275,7 +275,8 @@ class LAS(ModelProto):
         ws.demb = f(U * B, Hd)
         ws.denc, ws.dKq, ws.dK, ws.ds0 = f(B * T2, 2 * He), f(B * T2, Hd), f(B * T2, Hd), f(B * T2, 1)
         ws.dhs, ws.dcs = f(B, Hd), f(B, Hd)
-        ws.dz, ws.dy = f(B * T2, 2 * He), f(B, T2, 2 * He)
+        ws.dz = [f(B * T2, 2 * He) for _ in self.enc_layers]      # one per layer: layer i's projection gradient may still read its dz beside
+        ws.dy = f(B, T2, 2 * He)                                  # the sweep while layer i-1's BatchNorm gradient is being written
         ws.dx = [f(B * T2, 2 * He), f(B * T2, 2 * He)]
         ws.dfin_h = [f(B, He), f(B, He)]
         ws.dc_enc = [f(B, He), f(B, He)]
@@ -469,15 +470,19 @@ class LAS(ModelProto):
                                      and torch.cuda.get_device_properties(ws.enc.device).multi_processor_count >= 256)
         return ok
 
+    def _decoder_sweep_bwd_buffers(self, ws):
+        if getattr(ws, "dsweep_bwd_ws", None) is None:
+            ws.dsweep_bwd_ws = ops.decoder_sweep_bwd_ws(self.Hd, 2 * self.He, ws.enc.device)
+            for j in range(self.Ld):
+                ws.dec[j]["ds"] = torch.empty_like(ws.dec[j]["saved"])
+        return ws.dsweep_bwd_ws
+
     def _decoder_sweep_bwd(self, ws):
         """The decoder loop of backward_decoder (las.py:282-288 differentiated, U-1 .. 0) in ONE launch: gate-sum gradients of both
         layers (out of place, ws.dec[j]["ds"]), score gradients ws.ds, context gradients ws.dctx, initial-state gradients
         ws.dhs / ws.dc_dec - what U x {cell backward x 2, context gradient, attention backward} leave behind."""
         p, B, U, Hd, He = self.store.p, ws.B, ws.U, self.Hd, self.He
-        if getattr(ws, "dsweep_bwd_ws", None) is None:
-            ws.dsweep_bwd_ws = ops.decoder_sweep_bwd_ws(Hd, 2 * He, ws.enc.device)
-            for j in range(self.Ld):
-                ws.dec[j]["ds"] = torch.empty_like(ws.dec[j]["saved"])
+        self._decoder_sweep_bwd_buffers(ws)
         rate = self.dropout
         dk = "attend_and_speller/decoder_layers/{}/cell/"
         d = _lib.DecoderSweepGrad()
@@ -573,6 +578,14 @@ class LAS(ModelProto):
             segs.append(lambda i=i: self.backward_encoder_layer(ws, audio, i))
         return segs
 
+    def bucket_schedule(self):
+        """Per backward segment, the gradient buckets that are complete when it ends.  With the overlap scheduler a stage's weight
+        gradients run beside the NEXT stage's sweep, so every bucket completes one segment later and the last two together."""
+        n = 2 + self.Le
+        if not self._ov.on:
+            return [[k] for k in range(n)]
+        return [[]] + [[k] for k in range(n - 2)] + [[n - 2, n - 1]]
+
     def backward_vocab(self, ws):
         """Vocabulary projection (las.py:291): its weight gradient and the gradient flowing into the decoder chain."""
         assert ws.training, "backward needs a training-mode forward"
@@ -582,12 +595,13 @@ class LAS(ModelProto):
         mk, _ = self._drops(ws, 0, U, True)
         y_last = ws.dec[-1]["y"].view(U * B, Hd)
         src = ws.yd if rate > 0 else y_last
-        # (the weight gradient - 16 M outputs nobody downstream reads - may run beside the dX product on a side stream)
-        self._side_dec.run(lambda: dense_bwd(src, None, ws.logits, g["attend_and_speller/feedforward/kernel"], g["attend_and_speller/feedforward/bias"]))
+        # (the weight gradient - 16 M outputs nobody downstream reads - is released beside the decoder's backward sweep)
+        self._ov.defer(lambda: dense_bwd(src, None, ws.logits, g["attend_and_speller/feedforward/kernel"], g["attend_and_speller/feedforward/bias"]))
         dense_bwd(src, p["attend_and_speller/feedforward/kernel"], ws.logits, None, None, ws.dyd)
         if rate > 0:
             ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
-        self._side_dec.join()
+        if getattr(self, "bucket_sync", False):
+            self._ov.side.join()
 
     def backward_decoder(self, ws):
         p, g = self.store.p, self.store.g
@@ -599,9 +613,12 @@ class LAS(ModelProto):
         # written over its saved activations) to the cells that fed it; `ws.ddirect` carries the part of
         # dh that bypasses the gates (pad-token rows, GRU z*dh) along the single state chain.
         swept = self._decoder_sweep_bwd_ok(ws)
-        if swept:
-            self._decoder_sweep_bwd(ws)                               # all U steps in one launch (decoder_sweep_bwd.hip)
+        ov = self._ov
+        if swept:                                                     # all U steps in one launch (decoder_sweep_bwd.hip), the vocabulary
+            gate = ops.sweep_diag_words(self._decoder_sweep_bwd_buffers(ws), decoder=True)
+            ov.beside(lambda: self._decoder_sweep_bwd(ws), gate)      # layer's weight gradient beside it
         else:
+            ov.flush(join=False)
             if rt == "lstm":
                 ops.fill(ws.dc_dec, 0.0)
             ops.fill(ws.ddirect, 0.0)
@@ -655,32 +672,35 @@ class LAS(ModelProto):
             lin.direct, lin.direct_ld = ws.ddirect.data_ptr(), ws.ddirect.stride(0)
             lin.out, lin.out_ld = ws.dhs.data_ptr(), ws.dhs.stride(0)
             ops.rnn_cell_bwd(rt, B, [lin], None)
-        # ---- decoder weight gradients, batched over steps
-        for j in range(self.Ld):
-            pre = f"attend_and_speller/decoder_layers/{j}/cell/"
-            ds2 = (ws.dec[j]["ds"] if swept else ws.dec[j]["saved"]).view(U * B, -1)
-            gW, gU, gb = g[pre + "kernel"], g[pre + "recurrent_kernel"], g[pre + "bias"]
-            if j == 0:
-                hprev = ws.hin[:U].view(U * B, Hd)
-                emb = ws.emb.view(U * B, Hd)
-                xin = ws.ctx.view(U * B, 2 * He)
-                if rate > 0:
-                    xd = ws.xdrop[:, :2 * He]
-                    ops.dropout_rows(xin, xd, self.seed, mk(2, Hd + 2 * He, Hd))
-                    xin = xd
-                cell_param_grads(rt, Hd, emb, hprev, ds2, gW[:Hd], gU, gb)
-                cell_param_grads(rt, Hd, xin, None, ds2, gW[Hd:], None, None)
-                cell_input_grad(rt, Hd, ds2, p[pre + "kernel"][:Hd], ws.demb)
-                ops.embedding_bwd(g["attend_and_speller/embedding/embeddings"], ws.toks_T[:U], ws.demb, seed, mk(0, Hd), mk(2, Hd + 2 * He))
-            else:
-                hprev = ws.dec[j - 1]["h"].view(U * B, Hd)
-                xin = ws.dec[j - 1]["y"].view(U * B, Hd)
-                if rate > 0:
-                    xd = ws.xdrop[:, :Hd]
-                    ops.dropout_rows(xin, xd, self.seed, mk(2 + j, Hd))
-                    xin = xd
-                cell_param_grads(rt, Hd, xin, hprev, ds2, gW, gU, gb)
-        # ---- attention: batched key-side gradients (las.py:46-59, hoisted form)
+        # ---- decoder weight gradients, batched over steps: nothing downstream reads them before Adam - released beside the top
+        # encoder layer's backward sweep (layers.Overlap)
+        def decoder_weight_grads():
+            for j in range(self.Ld):
+                pre = f"attend_and_speller/decoder_layers/{j}/cell/"
+                ds2 = (ws.dec[j]["ds"] if swept else ws.dec[j]["saved"]).view(U * B, -1)
+                gW, gU, gb = g[pre + "kernel"], g[pre + "recurrent_kernel"], g[pre + "bias"]
+                if j == 0:
+                    hprev = ws.hin[:U].view(U * B, Hd)
+                    emb = ws.emb.view(U * B, Hd)
+                    xin = ws.ctx.view(U * B, 2 * He)
+                    if rate > 0:
+                        xd = ws.xdrop[:, :2 * He]
+                        ops.dropout_rows(xin, xd, self.seed, mk(2, Hd + 2 * He, Hd))
+                        xin = xd
+                    cell_param_grads(rt, Hd, emb, hprev, ds2, gW[:Hd], gU, gb)
+                    cell_param_grads(rt, Hd, xin, None, ds2, gW[Hd:], None, None)
+                    cell_input_grad(rt, Hd, ds2, p[pre + "kernel"][:Hd], ws.demb)
+                    ops.embedding_bwd(g["attend_and_speller/embedding/embeddings"], ws.toks_T[:U], ws.demb, seed, mk(0, Hd), mk(2, Hd + 2 * He))
+                else:
+                    hprev = ws.dec[j - 1]["h"].view(U * B, Hd)
+                    xin = ws.dec[j - 1]["y"].view(U * B, Hd)
+                    if rate > 0:
+                        xd = ws.xdrop[:, :Hd]
+                        ops.dropout_rows(xin, xd, self.seed, mk(2 + j, Hd))
+                        xin = xd
+                    cell_param_grads(rt, Hd, xin, hprev, ds2, gW, gU, gb)
+        ov.defer(decoder_weight_grads)
+        # ---- attention: batched key-side gradients (las.py:46-59, hoisted form); the products that lead to d enc first
         a = "attend_and_speller/attention/"
         Wq, bq, Wk = p[a + "query_weight/kernel"], p[a + "query_weight/bias"], p[a + "key_weight/kernel"]
         ds_b = ws.ds.permute(1, 0, 2)                      # [B, U, T2] views of the step-major buffers
@@ -690,20 +710,32 @@ class LAS(ModelProto):
         ops.gemm(ws.p.permute(1, 0, 2), ws.dctx.permute(1, 0, 2), ws.denc.view(B, T2, 2 * He), trans_a=True)  # p^T dctx
         ops.gemm(ws.dKq, Wq, ws.dK)                                                       # dK = dKq Wq
         ops.gemm(ws.ds0, bq.view(1, Hd), ws.dK, accumulate=1)                             #    + ds0 (x) bq
-        ops.gemm(ws.dKq, ws.K, g[a + "query_weight/kernel"], trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
-        ops.gemm(ws.K, ws.ds0, g[a + "query_weight/bias"].view(Hd, 1), trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
-        dense_bwd(ws.enc, Wk, ws.dK, g[a + "key_weight/kernel"], g[a + "key_weight/bias"], ws.denc, dx_accumulate=True)
-        # ---- listener state projections (las.py:196-202)
+        dense_bwd(ws.enc, Wk, ws.dK, None, None, ws.denc, dx_accumulate=True)             # d enc += dK Wk^T
+
+        def attention_weight_grads():
+            ops.gemm(ws.dKq, ws.K, g[a + "query_weight/kernel"], trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
+            ops.gemm(ws.K, ws.ds0, g[a + "query_weight/bias"].view(Hd, 1), trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
+            dense_bwd(ws.enc, None, ws.dK, g[a + "key_weight/kernel"], g[a + "key_weight/bias"])
+        ov.defer(attention_weight_grads)
+        # ---- listener state projections (las.py:196-202): the gradients wrt the encoder's final states first
         nst = 2 if rt == "lstm" else 1
         fin = ws.final_states
-        for k, (name, dsrc) in enumerate((("hidden_states_proj", ws.dhs), ("cell_states_proj", ws.dc_dec))[:nst]):
-            W, gW, gb = p[f"listener/{name}/kernel"], g[f"listener/{name}/kernel"], g[f"listener/{name}/bias"]
-            ops.colsum(dsrc, gb)
+        projs = (("hidden_states_proj", ws.dhs), ("cell_states_proj", ws.dc_dec))[:nst]
+        for k, (name, dsrc) in enumerate(projs):
+            W = p[f"listener/{name}/kernel"]
             for d in range(2):
-                st_ = fin[d * nst + k]
-                ops.gemm(st_, dsrc, gW[d * He:(d + 1) * He], trans_a=True, accumulate=1)
                 dst = ws.dfin_h[d] if k == 0 else ws.dc_enc[d]
                 ops.gemm(dsrc, W[d * He:(d + 1) * He], dst, trans_b=True)
+
+        def state_proj_weight_grads():
+            for k, (name, dsrc) in enumerate(projs):
+                gW, gb = g[f"listener/{name}/kernel"], g[f"listener/{name}/bias"]
+                ops.colsum(dsrc, gb)
+                for d in range(2):
+                    ops.gemm(fin[d * nst + k], dsrc, gW[d * He:(d + 1) * He], trans_a=True, accumulate=1)
+        ov.defer(state_proj_weight_grads)
+        if getattr(self, "bucket_sync", False):
+            ov.side.join()
 
     def backward_encoder_layer(self, ws, audio, i):
         """Encoder layer i backwards (las.py:190-193): BatchNorm+ReLU, projection, BiRNN; the convolutions follow layer 0."""
@@ -715,16 +747,20 @@ class LAS(ModelProto):
         dfin = list(ws.dfin_h) if top else ws.dfin_next
         l, lw = self.enc_layers[i], ws.layers[i]
         bn = f"listener/batch_norm/{i}/"
-        ops.bn_bwd(lw["z"], lw["a"], da, lw["mean"], lw["rstd"], p[bn + "gamma"], ws.dz, g[bn + "gamma"], g[bn + "beta"], ws.bn_ws, relu=True)
+        ov, dz = self._ov, ws.dz[i]
+        ops.bn_bwd(lw["z"], lw["a"], da, lw["mean"], lw["rstd"], p[bn + "gamma"], dz, g[bn + "gamma"], g[bn + "beta"], ws.bn_ws, relu=True)
         y2 = lw["rnn"]["y"].view(B * T2, 2 * He)
-        dense_bwd(y2, p[f"listener/projection/{i}/kernel"], ws.dz, g[f"listener/projection/{i}/kernel"],
-                  g[f"listener/projection/{i}/bias"], ws.dy.view(B * T2, 2 * He))
+        # the projection's weight / bias gradients wait for this layer's sweep (beside it, with whatever the stage before left pending:
+        # the decoder's or the layer above's weight gradients); only its input gradient is on the critical path
+        ov.defer(lambda: dense_bwd(y2, None, dz, g[f"listener/projection/{i}/kernel"], g[f"listener/projection/{i}/bias"]))
+        dense_bwd(y2, p[f"listener/projection/{i}/kernel"], dz, None, None, ws.dy.view(B * T2, 2 * He))
         dx = ws.dx0 if i == 0 else ws.dx[i & 1].view(B, T2, 2 * He)
-        ws.dfin_next = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, side=self._side)
-        if getattr(self, "bucket_sync", False) or i == 0:
-            self._side.join()              # data parallel: this layer's gradients form a bucket, complete when the segment ends
+        ws.dfin_next = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, overlap=ov)   # this layer's dW / dU / db: beside the next sweep
         if i > 0:
+            if getattr(self, "bucket_sync", False):
+                ov.side.join()             # data parallel: what ran beside this layer's sweep is a complete bucket when the segment ends
             return
+        ov.flush(join=False)               # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # ---- convolutions (las.py:183-184)
         if rate > 0:
             ops.dropout_flat(ws.dx0, self.seed, R.STREAM_CONV2_DROP, rate)
@@ -736,6 +772,7 @@ class LAS(ModelProto):
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
         ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"])
+        ov.side.join()
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):

@@ -46,6 +46,16 @@ class ModelProto(metaclass=ABCMeta):
     def make_example(audio, tokens):
         """Make training example (MODEL_INPUT, Y_TRUE) from audio input and token output."""
 
+    def raise_on_sweep_timeout(self):
+        """Forward-only passes (search, evaluation, model(...)) run the one-launch sweeps too; their time-out flag is only folded into
+        the sticky error word by a training update.  Call this where the host synchronises anyway (it does): raises, and clears the
+        flag, if a hand-off timed out since the flag was last cleared - the outputs of those passes are invalid."""
+        flag = getattr(self.store, "err_flag", None) if self.store is not None else None
+        if flag is not None and float(flag[0]) != 0.0:
+            flag.zero_()
+            raise RuntimeError("one-launch recurrent sweep: an inter-workgroup hand-off timed out during a forward pass; its outputs are "
+                               "invalid (rerun with ASR_PERSISTENT_RNN=0 to use the per-step kernels)")
+
     # ---- Keras-method stand-ins used by run.train -------------------------------------------------
     def count_params(self):
         n = self.store.num_trainable() if self.store is not None else 0

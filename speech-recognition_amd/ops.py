@@ -449,14 +449,61 @@ def rnn_persist_error(ws) -> int:
     return int(ws[-32:].view(torch.int32)[0].item())
 
 
+def sweep_diag_words(ws, decoder=False):
+    """The 32 diagnosis words of a sweep workspace (csrc/sweep_common.h) as a float32 view: the last 32 floats of an encoder /
+    wide sweep workspace, 288 floats from the end of a decoder sweep workspace (256 per-workgroup records follow them)."""
+    n = ws.numel()
+    return ws[n - 288:n - 256] if decoder else ws[n - 32:]
+
+
+_ABORT_STAGE = {
+    "rnn_sweep_fwd": {1: "gather of h(t-1)", 3: "XCD-id exchange"},
+    "rnn_sweep_bwd": {1: "gather of the partial dh blocks", 2: "owner waiting for the other gather waves", 3: "publish wave waiting for the gather waves",
+                      4: "publish wave waiting for its contraction partners", 5: "XCD-id exchange"},
+    "rnn_sweep_wide": {1: "probe of h(t-1)", 2: "gather of h(t-1)"},
+    "decoder_sweep_fwd": {1: "gather of h1", 2: "gather of the chunk partials", 3: "gather of the context", 4: "gather of h0"},
+    "decoder_sweep_bwd": {1: "layer-1 gather", 2: "layer-0 gather", 3: "context-gradient gather"},
+}
+
+
+def sweep_diagnosis(ws, kind, decoder=False, clear=False):
+    """None when the last launch of the sweep that owns `ws` ended normally, else a dict describing its first time-out
+    (synchronises): the error word decoded (stage, step), the record of the first workgroup that gave up and the verdict
+    'absent workgroup' (arrivals < expected: a compute unit was held by another tenant for the whole spin limit) or 'lost
+    hand-off' (every workgroup was resident)."""
+    view = sweep_diag_words(ws, decoder).view(torch.int32)
+    w = view.cpu().tolist()
+    if w[0] == 0 and w[24] == 0:
+        return None
+    # the sticky record (words 16-24) survives later launches; the per-launch words describe the LAST launch only
+    rec, expected, sticky = (w[16:24], w[23], True) if w[24] else (w[8:16], w[5], False)
+    word = rec[0] if (sticky or w[15]) else w[0]
+    code, step = word & 255, ((word >> 8) & 0xFF) if decoder else ((word >> 8) & 0xFFFFFF)
+    out = dict(kernel=kind, error_word=word & 0xFFFFFFFF, stage=_ABORT_STAGE.get(kind, {}).get(code, f"LDS hand-over (code {code})"), step=step,
+               launches_that_gave_up=w[24], expected=expected)
+    if sticky or w[15]:
+        out.update(block=(rec[1] & 0xFFF, (rec[1] >> 12) & 0xFFF, (rec[1] >> 24) & 0xFF), xcc_id=rec[2], arrived=rec[3], local_mode=rec[4], wave=rec[5],
+                   verdict="absent workgroup" if 0 < expected and rec[3] < expected else "lost hand-off")
+    if clear:
+        view[16:25].zero_()
+    return out
+
+
+def sweep_gate(diag_words, max_us=300):
+    """One wave on the current stream that waits (at most max_us) until the sweep owning `diag_words` has all its workgroups
+    resident (asr_sweep_gate): put in front of work that is to run beside that sweep on another stream."""
+    check(lib().asr_sweep_gate(_p(diag_words), int(max_us), _stream()))
+
+
 def rnn_sweep_set_spin_limit(polls: int):
     """Polls before a hand-off of the one-launch sweeps gives up (tests force time-outs with 0)."""
     lib().asr_rnn_sweep_set_spin_limit(int(polls))
 
 
 def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None, err_flag=None):
-    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0.
-    persist_ws: scratch from rnn_persist_bwd_ws -> the one-launch sweep instead of one launch per step."""
+    """dirs_grad: list of dicts with keys dh_last, dc, dy_carry, direct ([B,H] scratch), dh0, ds.
+    persist_ws: scratch from rnn_persist_bwd_ws -> the one-launch sweep instead of one launch per step; the sweep writes the
+    gate-sum gradients to the `ds` tensors ([B,T,NS*H], not the saved activations), the per-step kernels over `saved`."""
     g = _lib.RnnSeqGrad()
     g.dy = dy.data_ptr()
     g.dy_ld = dy.stride(1)
@@ -467,6 +514,7 @@ def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None, err_flag=None):
     g.direct = _arr2([d.get("direct") for d in dirs_grad])
     g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
     g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
+    g.ds = _arr2([d.get("ds") for d in dirs_grad])
     if persist_ws is not None:
         check(lib().asr_rnn_sweep_bwd(C.byref(seq), C.byref(g), _p(persist_ws), _p(err_flag), _stream()))
     else:

@@ -64,6 +64,7 @@ class LAS_Searcher:
                 break
         # the reference leaves its loop as soon as every row has ended: keep the tokens up to the last EOS
         done = int(seq_len.max().item()) - 1 if bool(ended.all().item()) else steps
+        m.raise_on_sweep_timeout()                             # (the encoder ran as one-launch sweeps; the host has just synchronised)
         tokens = ws.toks_T[:done + 1].t().contiguous()
         perplexity = torch.exp(-log_ppl / seq_len.to(torch.float32))      # pow(exp(log_ppl), -1 / sequence_lengths)
         return tokens, perplexity
@@ -134,6 +135,7 @@ class LAS_Searcher:
             if (i + 1) % self.check_every == 0 and i + 1 < steps and bool(ended[cur].all().item()):
                 break
         L = int(final_len.item())
+        m.raise_on_sweep_timeout()
         tokens = hist[cur, :, :L].reshape(B, k, L)
         lengths = torch.where(ended[cur].bool(), slen[cur], torch.full_like(slen[cur], L)).view(B, k)
         keep = torch.arange(L, device=dev)[None, None, :] < lengths[..., None]
@@ -166,6 +168,7 @@ class DeepSpeechSearcher:
         check(load().asr_ctc_greedy(_p(flat), flat.stride(0), B, T2, V, self.blank_index, _p(best), _p(best_lp), _p(tokens), _p(lengths),
                                     _p(neg_sum), ops._stream()))
         width = max(int(lengths.max().item()), 0)
+        m.raise_on_sweep_timeout()
         out = tokens[:, :width].contiguous()
         probability = torch.exp(-neg_sum)
         if return_alignment:
@@ -184,6 +187,7 @@ class DeepSpeechSearcher:
         lsm = torch.empty(B * T2, V + 1, dtype=torch.float32, device=dev)
         check(load().asr_ctc_log_softmax(_p(flat), flat.stride(0), B * T2, V, self.blank_index, _p(lsm), ops._stream()))
         host = lsm.cpu()                                        # the prefix tree is walked on the host
+        m.raise_on_sweep_timeout()
         tokens = torch.empty(B, top_paths, T2, dtype=torch.int32)
         lengths = torch.empty(B, top_paths, dtype=torch.int32)
         log_prob = torch.empty(B, top_paths, dtype=torch.float32)

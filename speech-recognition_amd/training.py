@@ -108,6 +108,36 @@ def sync_replicas(model, world: int, group=None, src: int = 0):
         model.weights_changed()
 
 
+def sweep_diagnoses(ws, clear=True):
+    """What the one-launch sweeps of a model workspace have on record about hand-off time-outs (ops.sweep_diagnosis: stage, step,
+    first workgroup that gave up, 'absent workgroup' or 'lost hand-off'), one dict per sweep that gave up since the last call."""
+    out = []
+    for i, lw in enumerate(getattr(ws, "layers", [])):
+        buf = lw.get("rnn") if isinstance(lw, dict) else None
+        if not buf:
+            continue
+        for key, kind in (("persist_ws", "rnn_sweep_fwd"), ("persist_bwd_ws", "rnn_sweep_bwd"), ("wide_ws", "rnn_sweep_wide")):
+            if key in buf:
+                d = ops.sweep_diagnosis(buf[key], kind, clear=clear)
+                if d:
+                    out.append(dict(d, layer=i))
+    for key, kind in (("dsweep_ws", "decoder_sweep_fwd"), ("dsweep_bwd_ws", "decoder_sweep_bwd")):
+        w = getattr(ws, key, None)
+        if w is not None:
+            d = ops.sweep_diagnosis(w, kind, decoder=True, clear=clear)
+            if d:
+                out.append(d)
+    return out
+
+
+class SweepTimeout(RuntimeError):
+    """A hand-off of a one-launch sweep timed out; `.reports` holds sweep_diagnoses() of the affected workspace."""
+
+    def __init__(self, msg, reports):
+        super().__init__(msg)
+        self.reports = reports
+
+
 class TrainStep:
     def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
                  beta1=0.9, beta2=0.999, eps=1e-7, eval_frontend=None):
@@ -242,10 +272,15 @@ class TrainStep:
             segs = self._segments(c, teacher)
             buckets = m.store.bucket_views() if self.world > 1 else []
             assert self.world == 1 or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
+            # buckets complete when backward segment k ends (a model that runs a stage's weight gradients beside the next stage's sweep
+            # completes them one segment late: bucket_schedule)
+            done = m.bucket_schedule() if hasattr(m, "bucket_schedule") else [[k] for k in range(len(buckets))]
+            assert not buckets or sorted(b for d in done for b in d) == list(range(len(buckets))), "every bucket is reduced exactly once"
             for k, fn in enumerate(segs):
                 self._run_segment(c, teacher, k, fn)
                 if k >= 1 and buckets:
-                    self.exchange.reduce_async(buckets[k - 1])
+                    for b in done[k - 1]:
+                        self.exchange.reduce_async(buckets[b])
             self.exchange.wait()
             self._run_segment(c, teacher, "update", self._update)
         m.weights_changed()
@@ -267,6 +302,8 @@ class TrainStep:
                 c["n_samples"].copy_(n_samples, non_blocking=True)
             c["tokens"].copy_(tokens, non_blocking=True)
             m.set_targets(c["ws"], c["tokens"], c["labels"])
+            if getattr(m.store, "err_flag", None) is not None:
+                ops.fill(m.store.err_flag, 0.0)            # a time-out in this forward-only pass must be seen below, not erased by the next step
             if fe is not None:
                 if fe.cfg.sa_enable:
                     raise ValueError("evaluate: the evaluation front end must not apply SpecAugment")
@@ -274,28 +311,30 @@ class TrainStep:
             m.pack_weights()
             m.forward_ws(c["ws"], c["feats"], False, bool(use_teacher_forcing))
             m.loss_and_grad(c["ws"], c["labels"], 1.0)
-        return self.read_stats(c["ws"])
+        return self.read_stats(c["ws"], check_flag=True)
 
     def synchronize(self):
         self.stream.synchronize()
         if self.exchange.comm_stream is not None:
             self.exchange.comm_stream.synchronize()
 
-    def read_stats(self, ws):
+    def read_stats(self, ws, check_flag=False):
         """Host copy of [loss, #correct, #kept] (synchronises).  Also checks the model's sticky error word: if a hand-off of a
         one-launch recurrent sweep timed out in ANY step since the last check (on any rank), those steps were skipped (parameters,
-        moments and the step counter untouched) and this raises - a time-out is never silent and never trains on garbage."""
+        moments and the step counter untouched) and this raises - a time-out is never silent and never trains on garbage.
+        check_flag: also look at the step's own error flag (a forward-only pass - evaluate() - never reaches the update that folds
+        the flag into the sticky word)."""
         self.synchronize()
         st = self.model.state.cpu()
-        if int(st[2]) != 0:
+        flag = float(self.model.store.err_flag[0]) if (check_flag and getattr(self.model.store, "err_flag", None) is not None) else 0.0
+        if int(st[2]) != 0 or flag != 0.0:
             self.model.state[2] = 0
-            detail = ""
-            for lw in getattr(ws, "layers", []):
-                for key in ("persist_ws", "persist_bwd_ws"):
-                    pws = lw["rnn"].get(key) if isinstance(lw, dict) and "rnn" in lw else None
-                    code = ops.rnn_persist_error(pws) if pws is not None else 0
-                    if code:
-                        detail = f" (last launch: {key} gave up with code {code & 255} at step {code >> 8})"
-            raise RuntimeError("one-launch recurrent sweep: an inter-workgroup hand-off timed out (GPU shared with another job?); the "
-                               "affected training steps were skipped" + detail + "; rerun with ASR_PERSISTENT_RNN=0")
+            if flag != 0.0:
+                ops.fill(self.model.store.err_flag, 0.0)
+            reports = sweep_diagnoses(ws)
+            detail = "".join(f"\n  {r}" for r in reports)
+            what = "the affected training steps were skipped" if not check_flag else "the results of this pass are invalid"
+            raise SweepTimeout("one-launch recurrent sweep: an inter-workgroup hand-off timed out; " + what + detail +
+                               "\n  ('absent workgroup': a compute unit was held by another tenant for the whole spin limit; 'lost hand-off': all "
+                               "workgroups were resident) - rerun with ASR_PERSISTENT_RNN=0 to use the per-step kernels", reports)
         return [float(v) for v in ws.stats[:3].cpu()]

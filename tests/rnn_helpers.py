@@ -81,13 +81,15 @@ class HipBiRNN:
         if persistent:
             assert ops.rnn_persist_bwd_supported(self.rt, B, T, H, len(self.dirs))
             pws = ops.rnn_persist_bwd_ws(B, H, len(self.dirs))
+            for dd, g in zip(self.dirs, gds):                     # the sweep writes ds out of place, the step kernels over `saved`
+                g["ds"] = dd["ds"] = torch.empty_like(dd["saved"])
         ops.rnn_seq_bwd(self.seq, gpu(dy), gds, pws)
         if persistent:
             assert not ops.rnn_persist_error(pws), "persistent backward: a hand-off timed out"
         out = []
         for d, (dd, g) in enumerate(zip(self.dirs, gds)):
             W, U, b = [p.double() for p in self.params[d]]
-            ds = dd["saved"].double().cpu()                       # [B,T,NS*H] gate-sum gradients
+            ds = (dd["ds"] if persistent else dd["saved"]).double().cpu()      # [B,T,NS*H] gate-sum gradients
             hseq = dd["hseq"].double().cpu()
             h0 = dd["h0"].double().cpu() if "h0" in dd else torch.zeros(B, H, dtype=torch.float64)
             if dd["reverse"]:

@@ -141,7 +141,7 @@ def test_persistent_backward_matches_step_kernels(rt, B, T, D, H, masked):
         hip = HipBiRNN(rt, x, mask, fwd, bwd, init)
         hip.forward(persistent=persistent)
         grads = hip.backward(R, S, persistent=persistent)
-        res.append((grads, [dd["saved"].clone() for dd in hip.dirs]))
+        res.append((grads, [(dd["ds"] if persistent else dd["saved"]).clone() for dd in hip.dirs]))
     for d in range(2):
         assert_close(res[1][1][d], res[0][1][d], 2e-5, "ds")
         for k in res[0][0][d]:

@@ -58,25 +58,22 @@ def main():
             t_f = time_fn(lambda: ops.rnn_seq_fwd_persist(hip.seq, ws), args.iters)
             assert not ops.rnn_persist_error(ws), "forward hand-off timed out"
             y = hip.y.clone()
-            saved = [dd["saved"].clone() for dd in hip.dirs]
             gds = [dict(direct=torch.zeros(B, H, device="cuda"), dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"),
-                        dc=torch.zeros(B, H, device="cuda")) for _ in range(2)]
+                        dc=torch.zeros(B, H, device="cuda"), ds=torch.empty_like(dd["saved"])) for dd in hip.dirs]
             pws = ops.rnn_persist_bwd_ws(B, H, 2)
 
             def bwd_once():
-                for dd, sv, gd in zip(hip.dirs, saved, gds):
-                    dd["saved"].copy_(sv)           # the backward sweep overwrites the saved activations with ds
+                for gd in gds:
                     gd["dc"].zero_()
-                ops.rnn_seq_bwd(hip.seq, dy, gds, pws)
+                ops.rnn_seq_bwd(hip.seq, dy, gds, pws)      # (ds goes to its own buffers: the saved activations stay)
 
             def copy_only():
-                for dd, sv, gd in zip(hip.dirs, saved, gds):
-                    dd["saved"].copy_(sv)
+                for gd in gds:
                     gd["dc"].zero_()
 
             t_b = time_fn(bwd_once, args.iters) - time_fn(copy_only, args.iters)
             assert not ops.rnn_persist_error(pws), "backward hand-off timed out"
-            results[sweep] = (y, [dd["saved"].clone() for dd in hip.dirs], [gd["dh0"].clone() for gd in gds])
+            results[sweep] = (y, [gd["ds"].clone() for gd in gds], [gd["dh0"].clone() for gd in gds])
             loc = lambda w: tuple(int(v) for v in w[-32:].view(torch.int32)[2:4].tolist())     # (XCD-local workgroups, all)
             print(f"{name} {rt} B={B} T={T} H={H} sweep={int(sweep)}: fwd {t_f:8.1f} us = {t_f / T:5.2f} us/step   "
                   f"bwd {t_b:8.1f} us = {t_b / T:5.2f} us/step   XCD-local workgroups fwd {loc(ws)} bwd {loc(pws)}", flush=True)

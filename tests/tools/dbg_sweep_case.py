@@ -15,7 +15,7 @@ hip = HipBiRNN(rt, x, None, fwd, bwd, None)
 hip.forward(persistent=True)
 dy = torch.randn(B, T, 2 * H, generator=g).cuda()
 gds = [dict(direct=torch.zeros(B, H, device="cuda"), dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"),
-            dc=torch.zeros(B, H, device="cuda")) for _ in range(2)]
+            dc=torch.zeros(B, H, device="cuda"), ds=torch.empty_like(dd["saved"])) for dd in hip.dirs]
 pws = ops.rnn_persist_bwd_ws(B, H, 2)
 ops.rnn_seq_bwd(hip.seq, dy, gds, pws)
 torch.cuda.synchronize()
