@@ -339,6 +339,12 @@ typedef struct asr_rnn_seq {
   float* hseq[2]; float* cseq[2];
   float* y; long y_ld; int y_col[2];
   float* saved[2];
+  float* coef[2];                           /* one-launch sweeps only, or NULL: [B,T,H,CW] (CW = 8; SimpleRNN 4) the element-wise
+                                               backward of every (row, step, unit) folded into coefficients by the forward sweep -
+                                               LSTM {A, f, Co, m | Ci, Cf, Cg, 0}: dc' = dc + dh A, ds_i,f,g = dc' (Ci, Cf, Cg), ds_o = dh Co,
+                                               dc_prev = dc' f; GRU {Cz, Cr, E, E r | z, m}: ds = dh (.) (...), carried dh = dh z; m = step mask.
+                                               asr_rnn_sweep_fwd writes it (when non-NULL), asr_rnn_sweep_bwd reads it instead of
+                                               saved / cseq / hseq / mask: two 16-byte loads per unit and step instead of seven scalar ones */
 } asr_rnn_seq;
 int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream);
 typedef struct asr_rnn_seq_grad {
@@ -360,7 +366,9 @@ int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, void* strea
  * flags, no fences).  Forward: every workgroup owns 4 (or 8) hidden units x all gates and gathers h_{t-1} of its 16 batch rows;
  * backward: a square of workgroups per (direction, batch tile) splits ds x U^T over both its axes, so a workgroup publishes one
  * [16 x KU] block of partial dh and gathers 16 x H floats.  Same contracts as asr_rnn_seq_fwd / asr_rnn_seq_bwd (g->direct and
- * g->dy_carry are unused; results equal to fp32 rounding, the forward bit for bit).  Supported when H % 16 == 0, H <= 256,
+ * g->dy_carry are unused; results equal to fp32 rounding, the forward bit for bit), except for how the element-wise operands
+ * travel: asr_rnn_sweep_bwd reads s->coef (written by asr_rnn_sweep_fwd of the same layer when non-NULL) instead of saved /
+ * cseq / hseq / mask, and writes the gate-sum gradients to g->ds.  Supported when H % 16 == 0, H <= 256,
  * T >= 2 and the grid fits the chip (asr_rnn_sweep[_bwd]_supported); every spin is bounded.  ws: asr_rnn_sweep[_bwd]_ws_floats() floats, re-armed by every call; the uint32 at
  * ws[ws_floats - 32] is non-zero after the call if a hand-off timed out (results invalid); err_flag: optional device float
  * that is set to 1.0f in that case and never cleared by the library (TrainStep's sticky error cell).

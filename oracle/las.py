@@ -121,8 +121,10 @@ def listener(p, cfg, audio, training, seed=0):
     return x, mask, states, bn_updates
 
 
-def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=0, step=0):
-    """AttendAndSpeller.call (las.py:267-292) for one decoder step. Returns (logits, states, probs)."""
+def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=0, step=0, trace=None):
+    """AttendAndSpeller.call (las.py:267-292) for one decoder step. Returns (logits, states, probs).
+    trace: optional dict (tests) that receives this step's context, masked attention scores and per-layer cell states with
+    retain_grad(), so that the gradients the HIP backward sweep writes out can be read after backward()."""
     rt, rate, nd = cfg["rnn_type"], float(cfg["dropout"]), cfg["num_decoder_layers"]
     pad = cfg.get("pad_id", 0)
     dt = enc.dtype
@@ -133,8 +135,14 @@ def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=
     if training and rate > 0:
         x = x * L.dropout_mult(seed, base + 0, x.shape, rate, dt)
     a = "attend_and_speller/attention/"
-    ctx, probs = L.attention(states[0], enc, enc, attention_mask, p[a + "query_weight/kernel"],
-                             p[a + "query_weight/bias"], p[a + "key_weight/kernel"], p[a + "key_weight/bias"])
+    ctx, probs, scores = L.attention(states[0], enc, enc, attention_mask, p[a + "query_weight/kernel"],
+                                     p[a + "query_weight/bias"], p[a + "key_weight/kernel"], p[a + "key_weight/bias"], return_scores=True)
+    if trace is not None:
+        for t_ in (ctx, scores):
+            if t_.requires_grad:
+                t_.retain_grad()
+        trace.setdefault("ctx", []).append(ctx)
+        trace.setdefault("scores", []).append(scores)
     x = torch.cat([x, ctx], dim=-1)
     for j in range(nd):
         pre = f"attend_and_speller/decoder_layers/{j}/cell/"
@@ -144,6 +152,11 @@ def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=
         out, states = L.rnn_layer(rt, x[:, None, :], m, p[pre + "kernel"], p[pre + "recurrent_kernel"],
                                   p[pre + "bias"], initial_state=states, in_mult=im)
         x = out[:, -1]                                           # return_sequences=False: last output
+        if trace is not None:
+            trace.setdefault(f"y{j}", []).append(x)
+            trace.setdefault(f"h{j}", []).append(states[0])
+            if len(states) > 1:
+                trace.setdefault(f"c{j}", []).append(states[1])
     if training and rate > 0:
         x = x * L.dropout_mult(seed, base + 1, x.shape, rate, dt)
     logits = x @ p["attend_and_speller/feedforward/kernel"] + p["attend_and_speller/feedforward/bias"]
@@ -157,16 +170,22 @@ def las_forward(p, cfg, audio, tokens, training=False, seed=0, use_teacher_forci
     U = tokens.shape[1]
     outs, probs_all = [], []
     logits = None
+    trace = {} if return_aux else None
+    init_states = list(states)
+    if return_aux:
+        for t_ in init_states:
+            if t_.requires_grad:
+                t_.retain_grad()
     for i in range(U):
         if use_teacher_forcing or i == 0:
             tok = tokens[:, i]
         else:
             tok = logits.argmax(dim=-1)
-        logits, states, probs = attend_and_speller(p, cfg, enc, tok, mask, states, training, seed, i)
+        logits, states, probs = attend_and_speller(p, cfg, enc, tok, mask, states, training, seed, i, trace)
         outs.append(logits)
         probs_all.append(probs)
     out = torch.stack(outs, dim=1)
     if return_aux:
         return out, {"enc": enc, "mask": mask, "bn_updates": bn_updates, "probs": torch.stack(probs_all, 1),
-                     "states": states}
+                     "states": states, "init_states": init_states, "trace": trace}
     return out

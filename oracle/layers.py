@@ -151,10 +151,13 @@ def batch_norm(x, gamma, beta, moving_mean, moving_var, training, eps=1e-3, mome
 # --------------------------------------------------------------------------------------
 # "AdditiveAttention" (las.py:46-59): projected dot-product attention, no tanh / v.
 # --------------------------------------------------------------------------------------
-def attention(query, key, value, attention_mask, Wq, bq, Wk, bk):
+def attention(query, key, value, attention_mask, Wq, bq, Wk, bk, return_scores=False):
     q = (query @ Wq + bq)[:, None, :]                       # [B,1,H]
     k = (key @ Wk + bk).transpose(1, 2)                     # [B,H,T]
     w = q @ k                                               # [B,1,T]
     w = w - 1e9 * (1.0 - attention_mask[:, None, :].to(w.dtype))
     p = torch.softmax(w, dim=-1)
-    return (p @ value)[:, 0, :], p[:, 0, :]
+    ctx = (p @ value)[:, 0, :]
+    if return_scores:                                       # (tests: the masked scores, to read their gradient after backward())
+        return ctx, p[:, 0, :], w
+    return ctx, p[:, 0, :]

@@ -72,7 +72,7 @@ class RnnSeq(C.Structure):
                 ("bias_rec", c_f32p * 2), ("h0", c_f32p * 2), ("h0_ld", c_long * 2), ("c0", c_f32p * 2),
                 ("c0_ld", c_long * 2), ("rec_mult", c_f32p * 2), ("mask", c_f32p),
                 ("hseq", c_f32p * 2), ("cseq", c_f32p * 2), ("y", c_f32p), ("y_ld", c_long), ("y_col", C.c_int * 2),
-                ("saved", c_f32p * 2)]
+                ("saved", c_f32p * 2), ("coef", c_f32p * 2)]
 
 
 class DecoderSweep(C.Structure):

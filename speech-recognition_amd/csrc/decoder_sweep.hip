@@ -130,6 +130,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
       if (jb < KBH) bwh[i] = wp[(long)(kbase_h + jb) * 64];
     }
   }
+  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) *abort_flag = 15;   // the whole grid is resident before the first step
   __syncthreads();
 
   float* xb = a.xbuf;
@@ -505,9 +506,21 @@ static void ds_layout(int Hd, int D, long* o_h1, long* o_c1, long* o_h0, long* o
 extern "C" int asr_decoder_sweep_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D) {
   if (rnn_type != 0 || num_layers != 2 || B <= 0 || B > 32 || U < 1 || T2 < 1 || T2 > DS_NC * DS_MAXTC) return 0;
   if (Hd <= 0 || Hd % 16 != 0 || Hd > 256 || D <= 0 || D % 32 != 0 || D > 512) return 0;
+  // 256 workgroups that wait for each other, ~100 KB of LDS each: one per compute unit, all resident at once.  The occupancy answer
+  // is a query, not a reservation (single tenant assumed: another process holding LDS on one CU stalls the grid until it leaves or
+  // the spin limit reports it - sweep_common.h says which); a device that cannot hold the grid even when empty is refused here
   static long cap = 0;
-  if (cap == 0) cap = asr_sweep_capacity(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), 320);
-  return 1;                                              // one workgroup per CU by its LDS footprint: 256 on a 256-CU device
+  if (cap == 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, cus = 0, per = 0;
+    cap = -1;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), 320, ds_lds_bytes(256, 512)) == hipSuccess)
+      cap = (long)per * cus;
+    (void)hipGetLastError();
+  }
+  if (cap >= 0 && cap < 256) return 0;
+  return 1;
 }
 
 extern "C" long asr_decoder_sweep_ws_floats(int Hd, int D) {

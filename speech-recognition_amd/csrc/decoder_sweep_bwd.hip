@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
       *reinterpret_cast<float4*>(enc_s + t * ENLD + 4 * k4) = *reinterpret_cast<const float4*>(eng + (long)t * D + 4 * k4);
     }
   }
+  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) *abort_flag = 15;   // the whole grid is resident before the first step
   __syncthreads();
 
   float* xb = a.xbuf;

@@ -22,7 +22,11 @@
 // Wave roles: gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave that has just published
 // cannot consume the loads of its next gather before the write-through acknowledgement of that store has come back
 // (measured: +0.34 us per step).  The workgroup therefore has 4 GATHER waves (K split four ways: gather, MFMA, partial sums
-// to LDS; they never store to global memory) and NQ GATE waves (gate math, publish, re-arm, the layer's own outputs).
+// to LDS; they never store to global memory), NQ GATE waves (gate math, publish, re-arm) and ONE WRITER wave that stores the
+// layer's own outputs (h, y, c, saved activations / backward coefficients) a step behind, from records the gate waves leave in
+// LDS: in a gate wave those stores - to lines nobody has touched yet - would be retired by the `s_waitcnt vmcnt(0)` in front of
+// its NEXT publish (round 3: the forward sweep went from 467 to 506 us per las_small layer when the 16-byte coefficient
+// stores joined the gate waves' queue).
 // Compared with {value, tag} granules this halves the bytes every step moves across the fabric (16 KB instead of 32 KB
 // per workgroup at H = 256) and the number of load instructions per gather.
 // The buffer is filled with the sentinel before every launch; every spin is bounded: on time-out the workgroup raises
@@ -44,6 +48,7 @@ struct SwDir {
   const float* pre; const float* Wp; const float* bias_rec;
   const float* h0; long h0_ld; const float* c0; long c0_ld;
   float* hseq; float* cseq; float* saved;
+  float* coef;          // [B,T,H,CW] backward coefficients for the BPTT sweep (asr_rnn_seq.coef) or NULL
   int reverse, y_col;
 };
 struct SwArgs {
@@ -102,13 +107,16 @@ extern "C" int asr_sweep_gate(const float* diag_words, int max_microseconds, voi
   return ASR_OK;
 }
 
+#define SW_REC 16                  // floats of a gate lane's output record: h, y, c, -, saved[4], coefficients[8]
 template <int CELL, int NQ>
-__global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) {
+__global__ __launch_bounds__(64 * (5 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) {
   __shared__ float part[2][4][NQ][16 * 17];
+  __shared__ __attribute__((aligned(16))) float outs[2][NQ][64][SW_REC];   // by step parity: written by the gate waves, stored by the writer a step later
   __shared__ int abort_flag;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool gate_wave = wv < NQ;                       // waves [0, NQ): gate math + publish; waves [NQ, NQ + 4): gather + MFMA
-  const int wave = gate_wave ? 0 : wv - NQ;             // K-split index of a gather wave
+  const bool gate_wave = wv < NQ;                       // waves [0, NQ): gate math + publish; [NQ, NQ + 4): gather + MFMA; NQ + 4: writer
+  const bool gather_wave = wv >= NQ && wv < NQ + 4, writer_wave = wv == NQ + 4;
+  const int wave = gather_wave ? wv - NQ : 0;           // K-split index of a gather wave
   const int li = lane & 15, lq = lane >> 4;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gx = gridDim.x, gy = gridDim.y;
   if (a.xcd) {
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
 #pragma unroll
     for (int i = 0; i < SW_MAXB; ++i) {
       const int jb = wave + 4 * i;
-      bw[n][i] = jb < a.KB ? wp[(long)jb * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bw[n][i] = (gather_wave && jb < a.KB) ? wp[(long)jb * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   // float offset (inside a slot) of this lane's 16-byte piece of K block jb: slice 4jb+lq, row li
@@ -187,12 +195,42 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
     if (lane == 0) local_mode = same ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if (tid == 64 * NQ && !swd_wait_all(a.err, a.spin_limit)) abort_flag = 15;   // (a gather wave's lane: wave 0 may be busy with the id exchange)
   __syncthreads();
   const bool local = local_mode != 0 && !(a.dbg & 32);
   if (a.xcd && tid == 0) {                             // diagnosis: err[2] = workgroups that publish XCD-locally, err[3] = all
     atomicAdd(a.err + 2, local ? 1u : 0u);
     atomicAdd(a.err + 3, 1u);
   }
+
+  // writer wave: lane l stores the records of gate lane l of every gate wave (same (row, unit) mapping)
+  auto write_outputs = [&](int sp) {
+    const int tp = d.reverse ? T - 1 - sp : sp;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int jn = 4 * (q0 + n) + u;
+      if (b < B && jn < H) {
+        const float* rec = &outs[sp & 1][n][lane][0];
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rec);
+        const long bt = (long)b * T + tp, o = bt * H + jn;
+        d.hseq[o] = r0.x;
+        a.y[bt * a.y_ld + d.y_col + jn] = r0.y;
+        if (CELL == CELL_LSTM) d.cseq[o] = r0.z;
+        if (d.saved) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(rec + 4);
+          float* sv2 = d.saved + bt * NS * H + jn;
+          sv2[0] = sv.x;
+          if (NS == 4) { sv2[(long)H] = sv.y; sv2[2L * H] = sv.z; sv2[3L * H] = sv.w; }
+        }
+        if (d.coef) {
+          constexpr int CW = CELL == CELL_RNN ? 4 : 8;
+          float* cf = d.coef + o * CW;
+          *reinterpret_cast<f32x4*>(cf) = *reinterpret_cast<const f32x4*>(rec + 8);
+          if (CW == 8) *reinterpret_cast<f32x4*>(cf + 4) = *reinterpret_cast<const f32x4*>(rec + 12);
+        }
+      }
+    }
+  };
 
   for (int s = 0; s < T; ++s) {
     const int t = d.reverse ? T - 1 - s : s;
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
       for (int g = 0; g < NG; ++g) pre[g] = pr[(long)g * H];
     }
 
-    if (!gate_wave) {
+    if (gather_wave) {
     // A operand: 16 rows x H of h_{s-1}
     f32x4 av[SW_MAXB];
     if (s == 0) {
@@ -280,6 +318,7 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (abort_flag) break;
 
+    if (writer_wave && s > 0) write_outputs(s - 1);       // the records of step s - 1 are complete (the gate waves passed this barrier after writing them)
     if (gate_wave) {
       float hnew = hp;
       float sgv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -321,20 +360,44 @@ __global__ __launch_bounds__(64 * (4 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
               "global_store_dwordx4 %2, %3, off sc1" ::"v"(dst), "v"(pub), "v"(rearm), "v"(sent) : "memory");
       }
       if (live) {
-        const long o = ((long)b * T + t) * H + j;
-        d.hseq[o] = hnew;
-        a.y[((long)b * T + t) * a.y_ld + d.y_col + j] = yp;
-        if (CELL == CELL_LSTM) d.cseq[o] = cn;
-        if (d.saved) {
-          float* sv2 = d.saved + ((long)b * T + t) * NS * H + j;
-#pragma unroll
-          for (int g = 0; g < NS; ++g) sv2[(long)g * H] = sgv[g];
+        // this step's outputs as a record in LDS; the writer wave stores them after the next barrier
+        float* rec = &outs[s & 1][wv][lane][0];
+        *reinterpret_cast<f32x4*>(rec) = (f32x4){hnew, yp, cn, 0.f};
+        if (d.saved) *reinterpret_cast<f32x4*>(rec + 4) = (f32x4){sgv[0], sgv[1], sgv[2], sgv[3]};
+        if (d.coef) {
+          // the element-wise backward of this (row, step, unit) as coefficients (asr_rnn_seq.coef): everything the BPTT sweep would
+          // otherwise recompute from seven scalar loads per unit and step (four activations, c_t, c_{t-1} / h_{t-1}, the mask) on ITS
+          // critical path; here it is a dozen multiplications behind the publish.  A masked step carries the state gradients through
+          f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (CELL == CELL_LSTM) {
+            if (m) {
+              const float ig = sgv[0], fg = sgv[1], gg = sgv[2], og = sgv[3], tc = tanhf_(cn);
+              k0 = (f32x4){og * (1.f - tc * tc), fg, tc * og * (1.f - og), 1.f};
+              k1 = (f32x4){gg * ig * (1.f - ig), cp * fg * (1.f - fg), ig * (1.f - gg * gg), 0.f};
+            } else {
+              k0.y = 1.f;
+            }
+          } else if constexpr (CELL == CELL_GRU) {
+            if (m) {
+              const float z = sgv[0], r = sgv[1], hh = sgv[2], arh = sgv[3];
+              const float e = (1.f - z) * (1.f - hh * hh);
+              k0 = (f32x4){(hp - hh) * z * (1.f - z), e * arh * r * (1.f - r), e, e * r};
+              k1 = (f32x4){z, 1.f, 0.f, 0.f};
+            }
+          } else {
+            if (m) k0 = (f32x4){1.f - hnew * hnew, 1.f, 0.f, 0.f};
+          }
+          *reinterpret_cast<f32x4*>(rec + 8) = k0;
+          *reinterpret_cast<f32x4*>(rec + 12) = k1;
         }
         cp = cn;
         hp = hnew;
       }
     }
   }
+  // the last step's records (every wave left the loop at the same barrier, by time-out or by count)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (writer_wave && !abort_flag && T > 0) write_outputs(T - 1);
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     swd_record(a.err, (unsigned)abort_flag, local ? 1 : 0);
@@ -361,7 +424,7 @@ static long sw_fwd_capacity(int rnn_type) {
     const void* k = rnn_type == CELL_LSTM ? reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_LSTM, NQ>)
                   : rnn_type == CELL_GRU ? reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_GRU, NQ>)
                                          : reinterpret_cast<const void*>(rnn_sweep_fwd_kernel<CELL_RNN, NQ>);
-    cache[rnn_type] = asr_sweep_capacity(k, 64 * (4 + NQ));
+    cache[rnn_type] = asr_sweep_capacity(k, 64 * (5 + NQ));
   }
   return cache[rnn_type];
 }
@@ -403,9 +466,9 @@ extern "C" int asr_rnn_sweep_supported(int rnn_type, int B, int T, int H, int nd
 
 template <int NQ>
 static void sw_launch(int rnn_type, dim3 grid, hipStream_t st, const SwArgs& a) {
-  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_LSTM, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
-  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_GRU, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
-  else hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_RNN, NQ>), grid, dim3(64 * (4 + NQ)), 0, st, a);
+  if (rnn_type == CELL_LSTM) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_LSTM, NQ>), grid, dim3(64 * (5 + NQ)), 0, st, a);
+  else if (rnn_type == CELL_GRU) hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_GRU, NQ>), grid, dim3(64 * (5 + NQ)), 0, st, a);
+  else hipLaunchKernelGGL((rnn_sweep_fwd_kernel<CELL_RNN, NQ>), grid, dim3(64 * (5 + NQ)), 0, st, a);
 }
 
 // Same contract as asr_rnn_seq_fwd (rnn.hip), one launch.  ws: asr_rnn_sweep_ws_floats() floats; the uint32 at
@@ -439,7 +502,7 @@ extern "C" int asr_rnn_sweep_fwd(const asr_rnn_seq* s, float* ws, float* err_fla
     SwDir& p = a.d[d];
     p.pre = s->pre[d]; p.Wp = s->Wp[d]; p.bias_rec = s->bias_rec[d];
     p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
-    p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d];
+    p.hseq = s->hseq[d]; p.cseq = s->cseq[d]; p.saved = s->saved[d]; p.coef = s->coef[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];
   }
   const int nq = sw_nq(B, H, s->ndir);

@@ -54,10 +54,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct SbDir {
   const float* U; long ldu;
-  const float* saved;           // [B,T,NS*H]: gate activations of the forward pass
-  float* ds;                    // [B,T,NS*H]: gate-sum gradients out (never the same buffer: see the kernel)
-  const float* hseq; const float* cseq;
-  const float* h0; long h0_ld; const float* c0; long c0_ld;
+  const float* coef;            // [B,T,H,CW]: the element-wise backward as coefficients, written by the forward sweep (asr_rnn_seq.coef)
+  float* ds;                    // [B,T,NS*H]: gate-sum gradients out (a buffer nobody in this launch reads)
   const float* dh_last; long dh_last_ld;
   float* dc;                    // [B,H] in: d/d final c, out: d/d initial c (LSTM)
   float* dh0; long dh0_ld;
@@ -159,6 +157,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     if (lane == 0) local_mode = same ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) abort_flag = 15;   // the whole grid is resident before the first step
   __syncthreads();
   const bool local = local_mode != 0 && !(a.dbg & 32);
   if (a.xcd && tid == 0) {                             // diagnosis: err[2] = workgroups that publish XCD-locally, err[3] = all
@@ -198,28 +197,22 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     const long pos_off = ((long)(un >> 4) * 64 + plq * 16 + (un & 15)) * 4;   // this position inside a block
     // element-wise operands are fetched one step ahead (a wave's loads retire in order: fetched at the top of their own step they
     // would sit in front of the gather's polls)
-    struct Operands { bool m; float svv[NS], cpv, cov, hpv, dyv; };
+    // (two 16-byte coefficient loads + dy per row instead of the seven / eight scalar loads of rounds 1-2 - activations, c_t, c_{t-1},
+    // mask: what the operand loads cost in front of the polls was measured at ~0.8 us of the 3.4 us step)
+    constexpr int CW = CELL == CELL_RNN ? 4 : 8;
+    struct Operands { f32x4 k0, k1; float dyv; };
     auto fetch = [&](int p, Operands (&o)[NT]) {
       const int step = T - 1 - p;
       const int t = d.reverse ? T - 1 - step : step;
-      const int tp = d.reverse ? t + 1 : t - 1;
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        o[r].m = true; o[r].cpv = 0.f; o[r].cov = 0.f; o[r].hpv = 0.f; o[r].dyv = 0.f;
-#pragma unroll
-        for (int g = 0; g < NS; ++g) o[r].svv[g] = 0.f;
+        o[r].k0 = (f32x4){0.f, 0.f, 0.f, 0.f}; o[r].k1 = (f32x4){0.f, 0.f, 0.f, 0.f}; o[r].dyv = 0.f;
         if (live[r] && p < T && !(a.dbg & 8)) {
           const long bt = (long)brow[r] * T + t;
-          o[r].m = a.mask ? a.mask[bt] != 0 : true;
-          const float* sv = d.saved + bt * NS * H + j;
-#pragma unroll
-          for (int g = 0; g < NS; ++g) o[r].svv[g] = sv[(long)g * H];
+          const float* cf = d.coef + (bt * H + j) * CW;
+          o[r].k0 = *reinterpret_cast<const f32x4*>(cf);
+          if (CW == 8) o[r].k1 = *reinterpret_cast<const f32x4*>(cf + 4);
           o[r].dyv = a.dy[bt * a.dy_ld + d.y_col + j];
-          if (CELL == CELL_LSTM) {
-            o[r].cov = d.cseq[bt * H + j];
-            o[r].cpv = step == 0 ? (d.c0 ? d.c0[(long)brow[r] * d.c0_ld + j] : 0.f) : d.cseq[((long)brow[r] * T + tp) * H + j];
-          }
-          if (CELL == CELL_GRU) o[r].hpv = step == 0 ? (d.h0 ? d.h0[(long)brow[r] * d.h0_ld + j] : 0.f) : d.hseq[((long)brow[r] * T + tp) * H + j];
         }
       }
     };
@@ -296,13 +289,11 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
       }
       // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
-      bool m[NT];
-      float svv[NT][NS], cpv[NT], cov[NT], hpv[NT], dyv[NT], addAv[NT];
+      f32x4 k0[NT], k1[NT];
+      float dyv[NT], addAv[NT];
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        m[r] = nxt[r].m; cpv[r] = nxt[r].cpv; cov[r] = nxt[r].cov; hpv[r] = nxt[r].hpv; dyv[r] = nxt[r].dyv; addAv[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NS; ++g) svv[r][g] = nxt[r].svv[g];
+        k0[r] = nxt[r].k0; k1[r] = nxt[r].k1; dyv[r] = nxt[r].dyv; addAv[r] = 0.f;
         if (p == 0 && live[r] && d.dh_last) addAv[r] = d.dh_last[(long)brow[r] * d.dh_last_ld + j];
       }
       float ds[NT][4];
@@ -316,32 +307,28 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
         float dir = 0.f;
         if (live[r]) {
-          if (!m[r]) {
+          const bool m = (CELL == CELL_LSTM ? k0[r].w : (CELL == CELL_GRU ? k1[r].y : k0[r].y)) != 0.f;   // the step mask rides in the coefficients
+          if (!m) {
             dir = dh_state;
             carry[r] += dyv[r];
           } else {
             const float dh = dh_state + dyv[r] + carry[r];
             carry[r] = 0.f;
-            if constexpr (CELL == CELL_LSTM) {
-              const float ig = svv[r][0], fg = svv[r][1], gg = svv[r][2], og = svv[r][3];
-              const float tc = tanhf_(cov[r]);
-              const float dct = dcv[r] + dh * og * (1.f - tc * tc);
-              ds[r][0] = dct * gg * ig * (1.f - ig);
-              ds[r][1] = dct * cpv[r] * fg * (1.f - fg);
-              ds[r][2] = dct * ig * (1.f - gg * gg);
-              ds[r][3] = dh * tc * og * (1.f - og);
-              dcv[r] = dct * fg;
-            } else if constexpr (CELL == CELL_GRU) {
-              const float z = svv[r][0], rr = svv[r][1], hh = svv[r][2], arh = svv[r][3];
-              const float dahh = dh * (1.f - z) * (1.f - hh * hh);
-              ds[r][0] = dh * (hpv[r] - hh) * z * (1.f - z);
-              ds[r][1] = dahh * arh * rr * (1.f - rr);
-              ds[r][2] = dahh;
-              ds[r][3] = dahh * rr;
-              dir = dh * z;
-            } else {
-              const float hn = svv[r][0];
-              ds[r][0] = dh * (1.f - hn * hn);
+            if constexpr (CELL == CELL_LSTM) {                      // k0 = {A, f, Co, m}, k1 = {Ci, Cf, Cg, 0}
+              const float dct = dcv[r] + dh * k0[r].x;
+              ds[r][0] = dct * k1[r].x;
+              ds[r][1] = dct * k1[r].y;
+              ds[r][2] = dct * k1[r].z;
+              ds[r][3] = dh * k0[r].z;
+              dcv[r] = dct * k0[r].y;
+            } else if constexpr (CELL == CELL_GRU) {                // k0 = {Cz, Cr, E, E r}, k1 = {z, m, 0, 0}
+              ds[r][0] = dh * k0[r].x;
+              ds[r][1] = dh * k0[r].y;
+              ds[r][2] = dh * k0[r].z;
+              ds[r][3] = dh * k0[r].w;
+              dir = dh * k1[r].x;
+            } else {                                                // k0 = {1 - h^2, m, 0, 0}
+              ds[r][0] = dh * k0[r].x;
             }
           }
           dirv[r] = dir;
@@ -537,12 +524,11 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 0;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   for (int d = 0; d < s->ndir; ++d) {
-    ASR_CHECK(s->saved[d] && s->U[d] && s->hseq[d] && (!lstm || (gs->dc[d] && s->cseq[d])), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d)", d);
-    ASR_CHECK(gs->ds[d] && gs->ds[d] != s->saved[d], ASR_ERR_ARG, "asr_rnn_sweep_bwd: g->ds[%d] must be a buffer of its own (the sweep cannot write ds over the saved activations)", d);
+    ASR_CHECK(s->coef[d] && s->U[d] && (!lstm || gs->dc[d]), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d): the BPTT sweep reads the coefficients the forward sweep wrote (s->coef)", d);
+    ASR_CHECK(gs->ds[d] && (const float*)gs->ds[d] != s->coef[d], ASR_ERR_ARG, "asr_rnn_sweep_bwd: g->ds[%d] missing", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
     SbDir& p = a.d[d];
-    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.saved = s->saved[d]; p.ds = gs->ds[d]; p.hseq = s->hseq[d]; p.cseq = s->cseq[d];
-    p.h0 = s->h0[d]; p.h0_ld = s->h0_ld[d]; p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
+    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.coef = s->coef[d]; p.ds = gs->ds[d];
     p.dh_last = gs->dh_last[d]; p.dh_last_ld = gs->dh_last_ld[d];
     p.dc = gs->dc[d]; p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];

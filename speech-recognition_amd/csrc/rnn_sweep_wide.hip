@@ -105,6 +105,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
         cp[m][h] = d.c0 ? d.c0[(long)row * d.c0_ld + j] : 0.f;
       }
     }
+  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) abort_flag = 15;   // the whole grid is resident before the first step
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
   const long dir_words = (long)blockIdx.z * DS_SLOTS * a.slot_words;

@@ -47,6 +47,22 @@ __global__ void sw_fill_kernel(uint32_t* p, size_t n, uint32_t v, uint32_t* zero
 __device__ __forceinline__ void swd_arrive(unsigned* err) {
   __hip_atomic_fetch_add(err + SWD_ARRIVED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one lane per workgroup, after the workgroup's own set-up and before its first step: wait until the whole grid has counted itself in.
+// The waits of the steps are bounded in POLLS (a lost hand-off shows within ~a second); this one is bounded in TIME and generously
+// (20 s of the 100 MHz s_memrealtime clock): a foreign kernel that holds compute units - an RCCL collective, a co-tenant - only
+// delays the launch, it does not fail it.  Separates the two failure modes for good: after this, every workgroup IS resident.
+// spin_limit <= 0 (the tests' forced time-outs) does not wait at all.  false = the grid did not assemble (the caller aborts).
+__device__ __forceinline__ bool swd_wait_all(unsigned* err, int spin_limit) {
+  if (spin_limit <= 0) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned expected = __hip_atomic_load(err + SWD_EXPECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned arrived = __hip_atomic_load(err + SWD_ARRIVED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived >= expected) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) return false;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 // one lane per workgroup, last thing in the kernel: the last one out re-arms the handshake for asr_sweep_gate
 __device__ __forceinline__ void swd_depart(unsigned* err) {
   const unsigned expected = __hip_atomic_load(err + SWD_EXPECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -247,6 +247,15 @@ class BiRNN:
             if rt == "lstm":
                 dd["cseq"] = f(B, T, H)
             buf["dirs"].append(dd)
+        # both one-launch sweeps take this layer: the forward sweep then leaves the element-wise backward of every (row, step, unit) as
+        # coefficients (asr_rnn_seq.coef) instead of the saved activations, and the BPTT sweep writes the gate-sum gradients into the
+        # pre-activation buffer (dead once the forward sweep has consumed it; GRU: a buffer of its own, 4 slots against 3 gates)
+        buf["coef_mode"] = bool(PERSISTENT_RNN and self.recurrent_dropout == 0 and T >= 2 and ops.rnn_persist_supported(rt, B, T, H, 2)
+                                and ops.rnn_persist_bwd_supported(rt, B, T, H, 2))
+        if buf["coef_mode"]:
+            for dd in buf["dirs"]:
+                dd["coef_buf"] = f(B, T, H * ops.rnn_coef_width(rt))
+                dd["ds"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
         return buf
 
     def final_states(self, buf):
@@ -287,7 +296,12 @@ class BiRNN:
         buf["x3d"] = x3d
         buf["drop"] = drop
         buf["rdrop"] = rdrop
-        buf["seq"] = ops.make_rnn_seq(rt, B, T, H, buf["dirs"], mask, buf["y"], [0, H])
+        coef = bool(buf.get("coef_mode")) and training
+        for dd in buf["dirs"]:
+            dd["coef"] = dd["coef_buf"] if coef else None
+        buf["coef_fwd"] = coef
+        seq_dirs = [dict(dd, saved=None) for dd in buf["dirs"]] if coef else buf["dirs"]     # (coefficients replace the saved activations)
+        buf["seq"] = ops.make_rnn_seq(rt, B, T, H, seq_dirs, mask, buf["y"], [0, H])
         # one persistent launch for all T steps when the layer fits on the chip, else one launch per step
         if PERSISTENT_RNN and not rdrop and ops.rnn_persist_supported(rt, B, T, H, 2):
             if "persist_ws" not in buf:
@@ -313,11 +327,9 @@ class BiRNN:
         backward sweep, and this layer's weight gradients are handed to it for the next sweep; the caller flush()es it."""
         B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
         pws = None
-        if PERSISTENT_RNN and not buf["rdrop"] and ops.rnn_persist_bwd_supported(rt, B, T, H, 2):
+        if buf.get("coef_fwd"):                          # the forward sweep left the coefficients the BPTT sweep reads
             if "persist_bwd_ws" not in buf:
                 buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
-                for dd in buf["dirs"]:                   # the sweep writes the gate-sum gradients out of place
-                    dd["ds"] = torch.empty_like(dd["saved"])
             pws = buf["persist_bwd_ws"]
         gds = []
         for d, dd in enumerate(buf["dirs"]):

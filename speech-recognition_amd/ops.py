@@ -409,7 +409,13 @@ def make_rnn_seq(rnn_type, B, T, H, dirs, mask, y, y_cols):
     s.y_ld = y.stride(1)
     s.y_col = (C.c_int * 2)(*(list(y_cols) + [0] * (2 - len(y_cols))))
     s.saved = _arr2([d.get("saved") for d in dirs])
+    s.coef = _arr2([d.get("coef") for d in dirs])
     return s
+
+
+def rnn_coef_width(rnn_type) -> int:
+    """Floats per (row, step, unit) of the backward-coefficient buffer the forward sweep writes for the BPTT sweep (asr_rnn_seq.coef)."""
+    return 4 if rnn_type == "rnn" else 8
 
 
 def rnn_seq_fwd(seq):
@@ -457,12 +463,13 @@ def sweep_diag_words(ws, decoder=False):
 
 
 _ABORT_STAGE = {
-    "rnn_sweep_fwd": {1: "gather of h(t-1)", 3: "XCD-id exchange"},
+    "rnn_sweep_fwd": {1: "gather of h(t-1)", 3: "XCD-id exchange", 15: "start handshake (the grid did not assemble)"},
     "rnn_sweep_bwd": {1: "gather of the partial dh blocks", 2: "owner waiting for the other gather waves", 3: "publish wave waiting for the gather waves",
-                      4: "publish wave waiting for its contraction partners", 5: "XCD-id exchange"},
-    "rnn_sweep_wide": {1: "probe of h(t-1)", 2: "gather of h(t-1)"},
-    "decoder_sweep_fwd": {1: "gather of h1", 2: "gather of the chunk partials", 3: "gather of the context", 4: "gather of h0"},
-    "decoder_sweep_bwd": {1: "layer-1 gather", 2: "layer-0 gather", 3: "context-gradient gather"},
+                      4: "publish wave waiting for its contraction partners", 5: "XCD-id exchange", 15: "start handshake (the grid did not assemble)"},
+    "rnn_sweep_wide": {1: "probe of h(t-1)", 2: "gather of h(t-1)", 15: "start handshake (the grid did not assemble)"},
+    "decoder_sweep_fwd": {1: "gather of h1", 2: "gather of the chunk partials", 3: "gather of the context", 4: "gather of h0",
+                          15: "start handshake (the grid did not assemble)"},
+    "decoder_sweep_bwd": {1: "layer-1 gather", 2: "layer-0 gather", 3: "context-gradient gather", 15: "start handshake (the grid did not assemble)"},
 }
 
 

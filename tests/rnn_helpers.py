@@ -33,8 +33,9 @@ class HipBiRNN:
                 ops.f32_to_bf16(Ug.view(-1), img)
                 self._images = getattr(self, "_images", []) + [img]
             cell = ops.PackedCell(rnn_type, H, [H]).pack([(Ug, True)])
+            # coef: the backward coefficients the forward SWEEP writes for the BPTT sweep (the per-step kernels use `saved` only)
             dd = dict(pre=pre, cell=cell, U=Ug, reverse=(d == 1), hseq=torch.zeros(B, T, H, device="cuda"),
-                      saved=torch.zeros(B, T, ns * H, device="cuda"))
+                      saved=torch.zeros(B, T, ns * H, device="cuda"), coef=torch.zeros(B, T, H * ops.rnn_coef_width(rnn_type), device="cuda"))
             if rnn_type == "lstm":
                 dd["cseq"] = torch.zeros(B, T, H, device="cuda")
             if rnn_type == "gru":

@@ -1,0 +1,240 @@
+"""Parity of the kernels bench.py times, at the sizes it times them, against the float64 oracle DIRECTLY:
+
+  * the headline step itself: las_small.yml + libri_config.yml at batch 32, 10 s clips, 64 decoder steps, SpecAugment and
+    dropout on - loss (1e-3) and every gradient - with all four one-launch sweeps asserted to have run (models/las.py:349-380);
+  * the two decoder sweeps at (B, T, U, He, Hd) = (32, 999, 12, 256, 256) against the oracle's own intermediate tensors -
+    attention weights, contexts, both cells' states and outputs forward; score / context / initial-state gradients backward -
+    not only against the per-step kernels they replace (models/las.py:267-292, 368-377);
+  * las_large (BASELINE configs[4]) at its real sequence geometry: one BiLSTM layer at B = 64, T' = 499, H = 1024 through the
+    weights-resident bf16 forward sweep and the staged backward step kernels, against an oracle that rounds the same operands
+    to bf16 (models/las.py:90-126 at las_large.yml); and a whole training step with U = 127 decoder steps.
+
+Tolerances as in tests/test_real_configs_gpu.py (f32 kernels against float64: loss 1e-3, gradients 5e-3 of each tensor's
+largest entry at full size; mixed precision: bf16 operand rounding, stated per assert).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import las as OLAS
+from oracle import layers as OL
+from oracle import measure as OM
+from tests import test_real_configs_gpu as RC
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------------------- the headline step, batch 32
+def test_las_small_yml_headline_step_batch_32_against_the_oracle():
+    """BASELINE configs[1] exactly as bench.py runs it (B = 32, 10 s, U = 64, SpecAugment + delta on the GPU, dropout 0.15, teacher
+    forcing): two 16-row batch tiles x H = 256 through the encoder sweeps (forward + BPTT) and both decoder sweeps."""
+    from speech_recognition_amd import layers, ops
+    from speech_recognition_amd.configs import get_model_config
+    assert layers.PERSISTENT_RNN
+    B = 32
+    mc = RC._yaml("las_small.yml")
+    dc, plan = RC._frontend()
+    seed = 90417
+    audio, n = RC._audio(B, 10.0, short={1: 7.3, 19: 4.1, 31: 9.2})
+    toks = RC._tokens(B, 65, mc["vocab_size"], ragged={2: 41, 17: 12, 30: 64})
+    feats, ref_feats = RC._features(plan, dc, audio, n, seed)
+    model = get_model_config(os.path.join(RC.CONFIGS, "las_small.yml")).create_model(seed=7)
+    model.build(80, 3)
+    model.state[1] = seed
+    leaves = RC._leaves(model)
+    t = torch.from_numpy(toks)
+    logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+    loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
+    loss_r.backward()
+    correct_r, count_r = OM.sparse_categorical_accuracy(t[:, 1:], logits_r.detach(), 0)
+
+    ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+    assert (ws.B, ws.T2, ws.U) == (32, 249, 64)
+    model.set_targets(ws, t.cuda(), labels)
+    ops.fill(model.store.grad, 0.0)
+    model.forward_ws(ws, feats, True, True)
+    assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), logits_r, 1e-3, "las_small B=32 training logits")
+    model.loss_and_grad(ws, labels)
+    model.backward_ws(ws, feats)
+    torch.cuda.synchronize()
+    st = ws.stats.cpu().numpy()
+    assert abs(st[0] - float(loss_r.detach())) < 1e-3, (st[0], float(loss_r.detach()))
+    assert st[2] == count_r and abs(st[1] - correct_r) <= 2
+    assert all(f and b for f, b in RC._persistent_layers(ws)), "encoder: the forward and BPTT sweeps the benchmark times"
+    assert getattr(ws, "_sweep_ok", False), "decoder: the forward sweep the benchmark times"
+    assert getattr(ws, "_sweep_bwd_ok", False), "decoder: the backward sweep the benchmark times"
+    assert not ops.decoder_sweep_error(ws.dsweep_ws) and not ops.decoder_sweep_error(ws.dsweep_bwd_ws)
+    assert float(model.store.err_flag[0]) == 0.0
+    RC._check_grads(model, leaves, 5e-3, RC.LAS_NAMED)
+
+
+# ---------------------------------------------------------------------------------------------- decoder sweeps vs the oracle's own tensors
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(32, 999, 12, 256, 256, 0.15), (19, 70, 6, 32, 32, 0.0)])
+def test_decoder_sweeps_against_the_oracle_directly(B, T, U, He, Hd, dropout):
+    """decoder_sweep_fwd / decoder_sweep_bwd outputs against oracle.las aux tensors: p, ctx, per-layer h / c / y forward; de (scores),
+    dctx, d(initial h, c) backward.  1e-4 of the largest entry forward (f32 softmax over 249 frames, 12 chained steps), 2e-4
+    backward."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.models import LAS
+    V = 97
+    cfg = dict(rnn_type="lstm", vocab_size=V, encoder_hidden_dim=He, decoder_hidden_dim=Hd, num_encoder_layers=1, num_decoder_layers=2,
+               dropout=dropout, teacher_forcing_rate=0.99, pad_id=0)
+    g = torch.Generator().manual_seed(B + T + U)
+    audio = torch.randn(B, T, 20, 3, generator=g)
+    audio[1, T // 2:] = 0.0
+    audio[B - 1, 3 * T // 4:] = 0.0
+    tokens = torch.randint(1, V, (B, U + 1), generator=g, dtype=torch.int32)
+    tokens[1, U // 2:] = 0
+    tokens[B - 2, U - 1:] = 0
+    seed = 77
+    m = LAS("lstm", V, He, Hd, 1, 2, dropout, 0.99, 0, seed=3).build(20, 3)
+    m.state[1] = seed
+    leaves = RC._leaves(m)
+    logits_r, aux = OLAS.las_forward(leaves, cfg, audio.double(), tokens[:, :-1], training=True, seed=seed, use_teacher_forcing=True, return_aux=True)
+    loss_r = OM.sparse_categorical_crossentropy(tokens[:, 1:], logits_r, 0)
+    loss_r.backward()
+    tr = aux["trace"]
+
+    ws, labels = m.train_workspace(B, T, U + 1)
+    m.set_targets(ws, tokens.cuda(), labels)
+    ops.fill(m.store.grad, 0.0)
+    ag = audio.cuda()
+    m.forward_ws(ws, ag, True, True)
+    m.loss_and_grad(ws, labels)
+    m.backward_ws(ws, ag)
+    torch.cuda.synchronize()
+    assert getattr(ws, "_sweep_ok", False) and getattr(ws, "_sweep_bwd_ok", False)
+    assert not ops.decoder_sweep_error(ws.dsweep_ws) and not ops.decoder_sweep_error(ws.dsweep_bwd_ws)
+    stack = lambda key: torch.stack([v.detach() for v in tr[key]], 0)              # step-major like the workspace
+    # forward
+    assert_close(ws.p, aux["probs"].detach().permute(1, 0, 2), 1e-4, "attention weights p")
+    assert_close(ws.ctx, stack("ctx"), 1e-4, "contexts")
+    assert_close(ws.dec[0]["h"], stack("h0"), 1e-4, "layer-0 states h")
+    assert_close(ws.dec[0]["c"], stack("c0"), 1e-4, "layer-0 states c")
+    assert_close(ws.dec[0]["y"], stack("y0"), 1e-4, "layer-0 outputs")
+    assert_close(ws.hin[1:], stack("h1"), 1e-4, "layer-1 states h")
+    assert_close(ws.cin[1:], stack("c1"), 1e-4, "layer-1 states c")
+    assert_close(ws.dec[1]["y"], stack("y1"), 1e-4, "layer-1 outputs")
+    # backward
+    de_r = torch.stack([v.grad[:, 0, :] for v in tr["scores"]], 0)
+    dctx_r = torch.stack([v.grad for v in tr["ctx"]], 0)
+    assert_close(ws.ds, de_r, 2e-4, "score gradients de")
+    assert_close(ws.dctx, dctx_r, 2e-4, "context gradients dctx")
+    assert_close(ws.dhs, aux["init_states"][0].grad, 2e-4, "gradient wrt the decoder's initial h")
+    assert_close(ws.dc_dec, aux["init_states"][1].grad, 2e-4, "gradient wrt the decoder's initial c")
+    assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- las_large at its sequence geometry
+def _bf16(t):
+    """Round to bf16 (nearest even) and back; gradients pass straight through (the kernels differentiate the unrounded product)."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _bilstm_bf16_operands(x, fwd, bwd):
+    """oracle.layers.birnn for an unmasked LSTM layer with the recurrent product's operands (h, U) rounded to bf16 - what the wide
+    forward sweep and the wide step kernels multiply under mixed precision (f32 accumulation; gate math, cell state and the input
+    projection exact).  Same cell, gate order and state threading as oracle.layers.lstm_cell / rnn_layer."""
+    B, T, _ = x.shape
+    outs = []
+    for (W, U, b), rev in ((fwd, False), (bwd, True)):
+        H = U.shape[0]
+        Ub = _bf16(U)
+        h = torch.zeros(B, H, dtype=x.dtype)
+        c = torch.zeros(B, H, dtype=x.dtype)
+        pre = x @ W + b
+        ys = [None] * T
+        for t in (range(T - 1, -1, -1) if rev else range(T)):
+            z = pre[:, t] + _bf16(h) @ Ub
+            i, f, g_, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), torch.sigmoid(z[:, 3 * H:])
+            c = f * c + i * g_
+            h = o * torch.tanh(c)
+            ys[t] = h
+        outs.append(torch.stack(ys, 1))
+    return torch.cat(outs, -1)
+
+
+def test_las_large_layer_wide_sweep_and_staged_backward_at_full_sequence_geometry():
+    """One BiLSTM layer at las_large's per-GPU batch and sequence length - B = 64, T' = 499 (20 s clips), H = 1024 - through
+    rnn_sweepw_fwd_kernel (bf16 weights resident) and rnn_step_bwd_staged_kernel under mixed precision.  Forward against the
+    oracle with bf16-rounded (h, U): 2e-3 of the largest entry (an h within rounding of a bf16 boundary may flip and moves the
+    next step's operand by 2^-9).  Backward (ds also rounded to bf16 in the kernel, 499 chained steps): relative L2 3e-2 per
+    gradient tensor, the bound the las_large step test uses for mixed precision scaled to one layer."""
+    from speech_recognition_amd import ops
+    from tests.rnn_helpers import HipBiRNN
+    from tests.test_rnn_gpu import make_params
+    B, T, D, H = 64, 499, 64, 1024
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    g = torch.Generator().manual_seed(2024)
+    fwd, bwd = make_params("lstm", D, H, g, 0.03)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    dy = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64) * 1e-2
+    leaves = [[w.clone().double().requires_grad_(True) for w in ps] for ps in (fwd, bwd)]
+    xr = x.clone().requires_grad_(True)
+    y_r = _bilstm_bf16_operands(xr, leaves[0], leaves[1])
+    (y_r * dy).sum().backward()
+    ops.set_mixed_precision(True)
+    try:
+        hip = HipBiRNN("lstm", x, None, fwd, bwd, None)
+        assert ops.rnn_sweep_wide_supported("lstm", B, T, H, 2)
+        wws = ops.rnn_sweep_wide_ws(B, H, 2)
+        ops.rnn_sweep_wide_fwd(hip.seq, wws)
+        torch.cuda.synchronize()
+        assert not ops.rnn_persist_error(wws), "wide sweep: a hand-off timed out"
+        assert_close(hip.y, y_r.detach(), 2e-3, "las_large layer outputs")
+        assert not ops.rnn_persist_bwd_supported("lstm", B, T, H, 2), "H = 1024 is beyond the f32 BPTT sweep: the staged step kernels run"
+        grads = hip.backward(dy, [None] * 4, persistent=False)
+    finally:
+        ops.set_mixed_precision(False)
+    for d, (gr, lv) in enumerate(zip(grads, leaves)):
+        for key, ref in (("dW", lv[0].grad), ("dU", lv[1].grad), ("db", lv[2].grad)):
+            got = gr[key].double().cpu()
+            l2 = float((got - ref).norm()) / float(ref.norm())
+            assert l2 < 3e-2, f"direction {d} {key}: relative L2 error {l2:.2e}"
+    dx = sum(gr["dx"] for gr in grads).double().cpu()
+    l2 = float((dx - xr.grad).norm()) / float(xr.grad.norm())
+    assert l2 < 3e-2, f"dx: relative L2 error {l2:.2e}"
+
+
+def test_las_large_yml_training_step_with_127_decoder_steps():
+    """las_large.yml under mixed precision (BASELINE configs[4]) with the benchmark's decoder length: 128-token rows = U = 127
+    steps of {attention over T', two 1024-wide LSTM cells, Dense(16000)} on the per-step kernels, B = 18, 4 s clips (T' = 99).
+    Loss within 3e-2, gradients within the mixed-precision bounds of test_las_large_yml_training_step_wide_kernels."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.configs import get_model_config
+    mc = RC._yaml("las_large.yml")
+    dc, plan = RC._frontend()
+    seed, B = 61, 18
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    audio, n = RC._audio(B, 4.0, short={3: 2.9, 17: 1.5}, seed=8)
+    toks = RC._tokens(B, 128, mc["vocab_size"], ragged={5: 77, 11: 30})
+    feats, ref_feats = RC._features(plan, dc, audio, n, seed)
+    ops.set_mixed_precision(True)
+    try:
+        model = get_model_config(os.path.join(RC.CONFIGS, "las_large.yml")).create_model(seed=13)
+        model.build(80, 3)
+        model.state[1] = seed
+        leaves = RC._leaves(model)
+        t = torch.from_numpy(toks)
+        logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+        loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
+        loss_r.backward()
+        ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+        assert ws.U == 127
+        model.set_targets(ws, t.cuda(), labels)
+        ops.fill(model.store.grad, 0.0)
+        model.pack_weights()
+        model.forward_ws(ws, feats, True, True)
+        assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), logits_r, 5e-2, "las_large U=127 training logits")
+        model.loss_and_grad(ws, labels)
+        model.backward_ws(ws, feats)
+        torch.cuda.synchronize()
+        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 3e-2, (float(ws.stats[0]), float(loss_r.detach()))
+        assert all("wide_ws" in lw["rnn"] for lw in ws.layers)
+        RC._check_grads(model, leaves, 4e-1, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
+                                              "attend_and_speller/decoder_layers/1/cell/kernel"), tol_l2=1.5e-1)
+    finally:
+        ops.set_mixed_precision(False)

@@ -177,6 +177,7 @@ def test_las_small_yml_training_step_at_full_geometry(B):
     assert st[2] == count_r and abs(st[1] - correct_r) <= 1          # an arg-max tie may flip one of the 243 positions
     assert all(f and b for f, b in _persistent_layers(ws)), "the encoder layers must run the persistent kernels the benchmark times"
     assert getattr(ws, "_sweep_ok", False), "the decoder steps must run as the one-launch decoder sweep the benchmark times"
+    assert getattr(ws, "_sweep_bwd_ok", False), "... and backwards as the one-launch backward decoder sweep"
     worst = _check_grads(model, leaves, 5e-3, LAS_NAMED)
     print(f"las_small B={B}: loss {st[0]:.5f} (oracle {float(loss_r):.5f}), worst gradient {worst}")
 
@@ -361,6 +362,7 @@ def test_las_whole_model_gradients_through_persistent_kernels(rt):
     assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3
     assert _persistent_layers(ws) == [(True, True)] * 2
     assert getattr(ws, "_sweep_ok", False) == (rt == "lstm"), "LSTM decoders run the one-launch decoder sweep"
+    assert getattr(ws, "_sweep_bwd_ok", False) == (rt == "lstm"), "... forwards and backwards"
     _check_grads(m, leaves, 2e-3)
     for n, v in m.buffers.items():
         assert_close(v, aux["bn_updates"][n], 1e-4, n)

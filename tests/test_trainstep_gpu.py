@@ -61,8 +61,14 @@ def _las_trainer(He=32, seed=3, use_graph=True):
     from speech_recognition_amd.models import LAS
     from speech_recognition_amd.training import TrainStep
     from speech_recognition_amd.utils import LRScheduler
-    model = LAS("lstm", 41, He, He, 2, 1, 0.1, 0.99, seed=seed).build(20, 3)
+    # two decoder layers: the shape the one-launch DECODER sweeps take (one layer falls back to the per-step kernels)
+    model = LAS("lstm", 41, He, He, 2, 2, 0.1, 0.99, seed=seed).build(20, 3)
     return TrainStep(model, LRScheduler(100, 1e-3, 1e-5), frontend=None, use_graph=use_graph), model
+
+
+def _all_sweeps_ran(ws):
+    return (all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers) and getattr(ws, "_sweep_ok", False)
+            and getattr(ws, "_sweep_bwd_ok", False))
 
 
 def _las_batch(B=18, T=62, L=5, seed=0):
@@ -83,7 +89,7 @@ def test_sweep_timeout_skips_the_update_and_surfaces_later():
     batch = _las_batch()
     for _ in range(2):
         ws = tr.step(*batch, use_teacher_forcing=True)
-    assert all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers)
+    assert _all_sweeps_ran(ws), "encoder sweeps (forward, BPTT) and both decoder sweeps must be the path under test"
     tr.read_stats(ws)
     before = model.store.flat.clone()
     m_before, it_before = model.store.adam_m.clone(), int(model.state[0])
@@ -99,8 +105,13 @@ def test_sweep_timeout_skips_the_update_and_surfaces_later():
     ws = tr.step(*batch, use_teacher_forcing=True)       # a good step: trains again, the error stays on record
     tr.synchronize()
     assert int(model.state[0]) == it_before + 1 and not torch.equal(model.store.flat, before)
-    with pytest.raises(RuntimeError, match="hand-off timed out"):
+    with pytest.raises(RuntimeError, match="hand-off timed out") as info:
         tr.read_stats(ws)
+    # the sticky records name the sweeps that gave up (the failing launches were three steps ago: the per-launch words are long re-armed)
+    kinds = {r["kernel"] for r in info.value.reports}
+    # (which sweeps give up with a limit of 0 polls depends on whether their first poll already finds the data: at least one does)
+    assert kinds and kinds <= {"rnn_sweep_fwd", "rnn_sweep_bwd", "decoder_sweep_fwd", "decoder_sweep_bwd"}, kinds
+    assert all(r["expected"] > 0 and r["launches_that_gave_up"] >= 1 and r["verdict"] in ("absent workgroup", "lost hand-off") for r in info.value.reports)
     assert np.isfinite(tr.read_stats(ws)[0])             # raised once, cleared
 
     tr2, model2 = _las_trainer(use_graph=True, seed=9)
@@ -136,6 +147,48 @@ def test_sweeps_survive_foreign_kernels_holding_compute_units():
     for i in range(2):
         ws2 = tr2.step(*batch, use_teacher_forcing=True)
         assert abs(tr2.read_stats(ws2)[0] - losses[i]) <= 1e-5 * abs(losses[i])
-    assert all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers)
+    assert _all_sweeps_ran(ws), "the decoder sweeps (one 96 KB workgroup per compute unit) are the grid most exposed to co-tenants"
     a, b = model.store.flat, model2.store.flat
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_evaluate_surfaces_a_sweep_timeout():
+    """evaluate() and stand-alone forward passes run the forward / decoder sweeps too, but never reach the update
+    that folds the step's error flag into the sticky word - a time-out there used to be silent and the validation loss was computed
+    from partly unwritten buffers.  evaluate() now clears the flag before its pass and checks it afterwards."""
+    from speech_recognition_amd import ops
+    tr, model = _las_trainer(use_graph=False)
+    batch = _las_batch()
+    ws = tr.step(*batch, use_teacher_forcing=True)
+    tr.read_stats(ws)
+    good = tr.evaluate(*batch, use_teacher_forcing=True)
+    assert np.isfinite(good[0])
+    before = model.store.flat.clone()
+    ops.rnn_sweep_set_spin_limit(0)
+    try:
+        with pytest.raises(RuntimeError, match="results of this pass are invalid"):
+            tr.evaluate(*batch, use_teacher_forcing=True)
+    finally:
+        ops.rnn_sweep_set_spin_limit(1 << 20)
+    again = tr.evaluate(*batch, use_teacher_forcing=True)     # the flag was cleared: the next pass is judged on its own
+    assert abs(again[0] - good[0]) <= 1e-6 * max(1.0, abs(good[0]))
+    assert torch.equal(model.store.flat, before)
+    ws = tr.step(*batch, use_teacher_forcing=True)            # and training goes on
+    assert np.isfinite(tr.read_stats(ws)[0]) and int(model.state[2]) == 0
+
+
+def test_search_surfaces_a_sweep_timeout():
+    """The encoder of a greedy search runs as one-launch sweeps: a time-out (its flag raised by the kernel) must raise, not decode
+    garbage.  (A forward sweep does not reliably give up even with a spin limit of 0 - its first poll is delayed and usually finds
+    the data - so the flag is raised by hand: what is under test is that the searcher looks at it.)"""
+    from speech_recognition_amd.models import LAS
+    from speech_recognition_amd.search import LAS_Searcher
+    model = LAS("lstm", 41, 32, 32, 2, 2, 0.0, 0.99, seed=3).build(20, 3)
+    audio = _las_batch()[0]
+    searcher = LAS_Searcher(model, 6, 1, 2, 0)
+    toks, _ = searcher.greedy_search(audio)
+    model.store.err_flag.fill_(1.0)                           # what a timed-out sweep leaves behind
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        searcher.greedy_search(audio)
+    toks2, _ = searcher.greedy_search(audio)                  # raised once, cleared
+    assert torch.equal(toks, toks2)

@@ -54,6 +54,10 @@ def main():
                 print(f"{name}: generation sweep={sweep} does not take this shape")
                 continue
             hip = HipBiRNN(rt, x, mask, fwd, bwd, None)
+            mode = os.environ.get("BENCH_SWEEP_OUT", "both")          # what the forward sweep writes for backward: both | saved | coef
+            if mode != "both":
+                drop = "coef" if mode == "saved" else "saved"
+                hip.seq = ops.make_rnn_seq(rt, B, T, H, [dict(dd, **{drop: None}) for dd in hip.dirs], hip.mask, hip.y, [0, H])
             ws = ops.rnn_persist_ws(B, H, 2)
             t_f = time_fn(lambda: ops.rnn_seq_fwd_persist(hip.seq, ws), args.iters)
             assert not ops.rnn_persist_error(ws), "forward hand-off timed out"
