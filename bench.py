@@ -38,6 +38,8 @@ WORKLOADS = {
     # algorithmic_bytes: activations kept for backward written once + read once (2 x 0.9 GB), logits 131 MB x 5 touches,
     # Adam 28 B x 16 M parameters, features 51 MB, every weight matrix read twice (forward product, input gradient)
     "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=2 * 6.17e9 + 3.74e9, algorithmic_bytes=3.1e9,
+                      traffic_source="offline rocprofv3 PMC passes, profiles/r02_las_small_pmc_hbm_traffic.txt (not measured in this run)",
+                      dominant_traffic=None,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
@@ -308,6 +310,39 @@ def kernel_rooflines(trainer, model, audio_d, n_d, precision):
     return out
 
 
+def quick_workload(wname, steps, use_graph):
+    """A short single-GPU measurement of another BASELINE workload (same step function, synthetic batch of ITS geometry): 3 warm-up
+    steps, `steps` timed ones bracketed by synchronize()."""
+    from speech_recognition_amd import ops
+    wl = WORKLOADS[wname]
+    precision = wl.get("precision", "f32")
+    ops.set_mixed_precision(precision == "bf16")
+    audio, n, toks = synthetic_batch(0, wl)
+    audio_d, n_d, toks_d = torch.from_numpy(audio).cuda(), torch.from_numpy(n).cuda(), torch.from_numpy(toks).cuda()
+    trainer, model = build_trainer(wl, None, use_graph=use_graph)
+    for _ in range(3):
+        ws = trainer.step(audio_d, n_d, toks_d, use_teacher_forcing=True)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(trainer.stream)
+    for _ in range(steps):
+        ws = trainer.step(audio_d, n_d, toks_d, use_teacher_forcing=True)
+    ev1.record(trainer.stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = trainer.read_stats(ws)                 # raises if a sweep timed out: the caller records the error instead of a number
+    dev_s = ev0.elapsed_time(ev1) * 1e-3 / steps
+    peak = PEAK_BF16_MFMA if precision == "bf16" else PEAK_F32_MFMA
+    res = {"metric": wl["metric"], "value": round(wl["batch"] * wl["clip_seconds"] * steps / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "dtype": precision, "workload": wl["text"] + "; " + PRECISION_TEXT[precision], "final_loss": round(stats[0], 4),
+           "roofline": {"bound": "mfma", "achieved": round(wl["flops"] / dev_s / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
+                        "frac": round(wl["flops"] / dev_s / peak, 4), "kernel": "whole training step"}}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +352,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel timing loops (clean rocprof call counts)")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short deepspeech / las_large measurements the default (las_small, one GPU) run appends as extra_workloads")
     ap.add_argument("--precision", choices=["f32", "bf16"], default=None,
                     help="default: f32 for las_small / deepspeech (the headline dtype), bf16 mixed precision for las_large (BASELINE configs[4])")
     args = ap.parse_args()
@@ -420,6 +457,33 @@ def main():
     value = world * wl["batch"] * wl["clip_seconds"] * args.steps / dt
     achieved = wl["flops"] / (dev_ms * 1e-3)
     peak = PEAK_BF16_MFMA if precision == "bf16" else PEAK_F32_MFMA
+    step_roof = {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                 "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"}
+    if wl.get("algorithmic_bytes"):
+        # the HBM view of the same step: algorithmic bytes (DESIGN.md 5) over the step time - the step is nowhere near either roof,
+        # it is bound by the dependent-step latency of its recurrent sweeps (the kernels list says where the time goes)
+        step_roof["algorithmic_bytes"] = int(wl["algorithmic_bytes"])
+        step_roof["hbm_frac"] = round(wl["algorithmic_bytes"] / (dev_ms * 1e-3) / PEAK_HBM, 4)
+    kernels = None
+    if world == 1 and not args.no_kernel_rooflines:
+        try:
+            kernels = kernel_rooflines(trainer, model, audio_d, n_d, precision)
+        except Exception as e:  # per-kernel extras must never take the measured line down
+            kernels = f"failed: {e}"
+    # `roofline` = the DOMINANT kernel of the step (largest share of kernel time in profiles/: the encoder BPTT sweep, three launches
+    # per las_small step), timed alone on the trainer's stream by HIP events just above; `roofline.step` = the whole step against
+    # the same roof; `roofline.kernels` = every timed kernel.  traffic: memory-side bytes per LAUNCH of that kernel from the offline
+    # rocprofv3 PMC passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), not measured in this run: traffic_source says where
+    roof = dict(step_roof)
+    dom = next((k for k in kernels if isinstance(k, dict) and k.get("kernel", "").startswith("rnn_sweep_bwd_kernel")), None) if isinstance(kernels, list) else None
+    if dom is not None:
+        roof = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"], "kernel": dom["kernel"],
+                "us_per_launch": dom["us"], "us_per_dependent_step": dom.get("us_per_dependent_step"),
+                "traffic": wl.get("dominant_traffic") if precision == "f32" else None, "traffic_source": wl.get("traffic_source"),
+                "note": "latency-bound: one launch = T' dependent steps of ~3 us; the recurrent product's flops over the launch time against the f32 MFMA peak"}
+    roof["step"] = dict(step_roof, traffic=wl.get("traffic") if precision == "f32" else None, traffic_source=wl.get("traffic_source"))
+    if kernels is not None:
+        roof["kernels"] = kernels
     out = {
         "metric": wl["metric"], "value": round(value, 1), "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 3),
@@ -427,22 +491,22 @@ def main():
         "config": {"workload": wl["text"] + "; " + PRECISION_TEXT[precision], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
                    "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "persistent_rnn": bool(_layers.PERSISTENT_RNN), "remeasured": retried,
                    "sweep_errors": sweep_errors, "overlap": bool(_layers.Overlap.enabled), "final_loss": round(loss, 4)},
-        "roofline": {"bound": "mfma", "achieved": round(achieved / 1e12, 3), "peak": peak / 1e12, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": wl.get("traffic") if precision == "f32" else None,
-                     "kernel": f"whole training step (algorithmic {wl['flops'] / 1e9:.1f} GFLOP/step, SURVEY.md 8d) over HIP-event step time"},
+        "roofline": roof,
     }
-    if wl.get("algorithmic_bytes"):
-        # the HBM view of the same step: algorithmic bytes (DESIGN.md 5) over the step time - the step is nowhere near either roof,
-        # it is bound by the dependent-step latency of its recurrent sweeps (the kernels list says where the time goes)
-        out["roofline"]["algorithmic_bytes"] = int(wl["algorithmic_bytes"])
-        out["roofline"]["hbm_frac"] = round(wl["algorithmic_bytes"] / (dev_ms * 1e-3) / PEAK_HBM, 4)
-    if world == 1 and not args.no_kernel_rooflines:
-        try:
-            out["roofline"]["kernels"] = kernel_rooflines(trainer, model, audio_d, n_d, precision)
-        except Exception as e:  # per-kernel extras must never take the measured line down
-            out["roofline"]["kernels"] = f"failed: {e}"
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    # BASELINE configs[3] / [4] at their single-GPU geometry, measured in the same driver-visible run (short, OUTSIDE the headline's
+    # timed region, after it): DeepSpeech2 f32 and las_large under mixed precision
+    if args.workload == "las_small" and world == 1 and not args.no_extra_workloads:
+        del trainer, model
+        torch.cuda.empty_cache()
+        out["extra_workloads"] = []
+        for wname, steps in (("deepspeech", 10), ("las_large", 4)):
+            try:
+                out["extra_workloads"].append(quick_workload(wname, steps, not args.no_graph))
+            except Exception as e:
+                out["extra_workloads"].append({"workload": wname, "error": str(e)})
+        _ops.set_mixed_precision(precision == "bf16")
     print(json.dumps(out))
 
 

@@ -411,7 +411,8 @@ int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, voi
  * tokmask [U,B]; outputs p [U,B,T2], ctx [U,B,D], hin/cin [U+1,B,Hd] (row i+1 = last layer's state after step i; row 0 in),
  * per layer y [U,B,Hd], saved gate activations [U,B,4Hd], and layer 0's state h0/c0 [U,B,Hd].  Dropout as in the per-step
  * kernels: layer j's input dropout uses stream drop_stream0 + drop_stream_step * i + 2 + j.
- * Supported (asr_decoder_sweep_supported): LSTM, 2 layers, B <= 32, Hd % 16 == 0 <= 256, D % 32 == 0 <= 512, T2 <= 256, a
+ * Supported (asr_decoder_sweep_supported): LSTM, 2 layers, B <= 64 (more than 32 rows run as two launches of <= 32), Hd % 16 == 0 <= 256,
+ * D % 32 == 0 <= 512, T2 <= 512 (chunks of up to 64 frames: 32 resident in LDS, the rest streamed from L2 every step), a
  * device with >= 256 compute units.  ws: asr_decoder_sweep_ws_floats() floats; error word / err_flag as for asr_rnn_sweep_fwd.
  * ------------------------------------------------------------------------------------------ */
 typedef struct asr_decoder_sweep {
@@ -439,7 +440,7 @@ int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, float* err_flag
  *   dh_init / dc_init [B,Hd]  gradients wrt the decoder's initial state.
  * U1/W1/U0/W0: recurrent_kernel and kernel of layers 1 and 0, row-major [rows, 4Hd] (W0 has Hd embedding rows, then D context rows).
  * Pad-token rows (tokmask 0) carry the state gradients through unchanged.  Supported (asr_decoder_sweep_bwd_supported): LSTM,
- * 2 layers, B <= 32, Hd in {16..128 step 16, 160..256 step 32}, D/4 a power of two <= 128 with D % (16 G) == 0 and D/G <= 64
+ * 2 layers, B <= 64 (passes of 32 rows), T2 <= 512 (as the forward sweep), Hd in {16..128 step 16, 160..256 step 32}, D/4 a power of two <= 128 with D % (16 G) == 0 and D/G <= 64
  * (G = Hd/16 or Hd/32), T2 <= 256, >= 256 compute units.  ws: asr_decoder_sweep_bwd_ws_floats() floats; error words as forward. */
 typedef struct asr_decoder_sweep_grad {
   int B, U, T2, Hd, D;

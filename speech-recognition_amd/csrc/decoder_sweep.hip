@@ -31,6 +31,7 @@
 
 struct DsArgs {
   int B, U, T2, Hd, D, TC, FS;            // FS = D / 8 features per context slice
+  int Bs, b0;                               // row stride of the step-major tensors / first batch row of this launch (batches > 32 run in passes)
   const float* Kq; const float* enc; const float* s0; const uint8_t* mask;
   const float* h_init; const float* c_init;
   const float* Wp0; int KSt0, kc0, kh0;    // layer 0 image: block offsets of the context and state segments
@@ -49,6 +50,10 @@ struct DsArgs {
   int prio;                                 // s_setprio level of every wave
 };
 
+// LONG: the general instance - chunks of more than DS_MAXTC frames (T' > 256: streamed-frame code) and / or a batch that runs in
+// passes (row stride != rows of this launch, row offset != 0).  The kernel sits at the 256-register limit: the common instance
+// (T' <= 256, B <= 32: the benchmark's) must not pay for the general paths in spills, so they are compiled only into LONG
+template <bool LONG>
 __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -56,6 +61,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   const int li = lane & 15, lq = lane >> 4;
   const int w = blockIdx.x;
   const int B = a.B, U = a.U, T2 = a.T2, Hd = a.Hd, D = a.D, TC = a.TC, FS = a.FS;
+  const int Bs_ = LONG ? a.Bs : B, b0_ = LONG ? a.b0 : 0;
   const int Q = Hd >> 2, KBH = Hd >> 4, KBC = D >> 4;
   // attention role
   const int ab = w >> 3, ac = w & 7;
@@ -69,15 +75,15 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   const int KQLD = Hd + 4, ENLD = D + 4;
   float* kq_s = lds;                                   // [TC][KQLD]
   float* enc_s = kq_s + DS_MAXTC * KQLD;               // [TC][ENLD]
-  float* s0m = enc_s + DS_MAXTC * ENLD;                // [32] score offsets: s0 - 1e9 (1 - mask)
-  float* hrow = s0m + 32;                              // [4 waves][Hd] the attention row of h1, one copy per gather wave
-  float* esc = hrow + 4 * 256;                         // [32] scores of the chunk
-  float* pt = esc + 32;                                // [4 waves][32] chunk-local exp(e - m_c), one copy per gather wave
-  float* pbuf = pt + 4 * 32;                           // [4 + D] partial to publish: {m_c, l_c, 0, 0}, ctx_c
+  float* s0m = enc_s + DS_MAXTC * ENLD;                // [64] score offsets: s0 - 1e9 (1 - mask)
+  float* hrow = s0m + DS_MAXTC2;                       // [4 waves][Hd] the attention row of h1, one copy per gather wave
+  float* esc = hrow + 4 * 256;                         // [64] scores of the chunk
+  float* pt = esc + DS_MAXTC2;                         // [4 waves][64] chunk-local exp(e - m_c), one copy per gather wave
+  float* pbuf = pt + 4 * DS_MAXTC2;                    // [4 + D] partial to publish: {m_c, l_c, 0, 0}, ctx_c
   float* sl = pbuf + 4 + 512;                          // [8][4 + FS] gathered stats + slices (FS <= 64)
   float* cslice = sl + 8 * 68;                         // [64] combined context slice
-  float* pn = cslice + 64;                             // [32] normalised probabilities of the chunk
-  float* part = pn + 32;                               // [2][4][16 * 17] matrix partial sums (double buffered by step parity)
+  float* pn = cslice + 64;                             // [64] normalised probabilities of the chunk
+  float* part = pn + DS_MAXTC2;                        // [2][4][16 * 17] matrix partial sums (double buffered by step parity)
   float* hblk = part + 2 * 4 * 272;                    // [64] previous state of the owned (row, unit) pairs
   float* cblk = hblk + 64;                             // [64] previous cell state of the owned pairs
   int* flags = reinterpret_cast<int*>(cblk + 64);      // abort | cC (slice ready) | per-wave progress words of the four hand-over points
@@ -85,22 +91,24 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   volatile int* cC = flags + 1;
   volatile int *cE = flags + 4, *cA = flags + 8, *cB = flags + 12, *cD = flags + 16;   // scores, partial, slices gathered, sums
   if (tid < 20) flags[tid] = 0;
+  if (tid < DS_MAXTC2) esc[tid] = -INFINITY;
   if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)
   swd_setprio(a.prio);
 
   // ---- resident operands ----
   if (attn) {
+    const int ntr = min(nt, DS_MAXTC);                  // frames resident in LDS; frames [ntr, nt) are read from memory every step
     const float* kqg = a.Kq + ((long)ab * T2 + t_lo) * Hd;
-    for (int i = tid; i < nt * (Hd >> 2); i += 320) {
+    const float* eng = a.enc + ((long)ab * T2 + t_lo) * D;
+    for (int i = tid; i < ntr * (Hd >> 2); i += 320) {
       const int t = i / (Hd >> 2), k4 = i % (Hd >> 2);
       *reinterpret_cast<float4*>(kq_s + t * KQLD + 4 * k4) = *reinterpret_cast<const float4*>(kqg + (long)t * Hd + 4 * k4);
     }
-    const float* eng = a.enc + ((long)ab * T2 + t_lo) * D;
-    for (int i = tid; i < nt * (D >> 2); i += 320) {
+    for (int i = tid; i < ntr * (D >> 2); i += 320) {
       const int t = i / (D >> 2), k4 = i % (D >> 2);
       *reinterpret_cast<float4*>(enc_s + t * ENLD + 4 * k4) = *reinterpret_cast<const float4*>(eng + (long)t * D + 4 * k4);
     }
-    if (tid < 32) {
+    if (tid < DS_MAXTC2) {
       float v = -INFINITY;                              // frames beyond the chunk take no part
       if (tid < nt) {
         const long bt = (long)ab * T2 + t_lo + tid;
@@ -205,6 +213,23 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         dot += __shfl_xor(dot, 2, 64);
         dot += __shfl_xor(dot, 4, 64);
         if (kg == 0) esc[t] = dot + s0m[t];
+        if (LONG && nt > DS_MAXTC) {                              // chunks longer than the LDS holds (T' > 256): the other frames' keys from memory
+          const int t2 = DS_MAXTC + t;
+          float dot2 = 0.f;
+          if (t2 < nt) {                                  // (addresses rebuilt here: nothing of the rare path stays live across the step)
+            const float* kr = a.Kq + ((long)ab * T2 + t_lo + t2) * Hd;
+            const float* hr = hrow + wave * 256;
+            for (int k4 = kg; k4 < (Hd >> 2); k4 += 8) {
+              const float4 kv = *reinterpret_cast<const float4*>(kr + 4 * k4);
+              const float4 hh = *reinterpret_cast<const float4*>(hr + 4 * k4);
+              dot2 += hh.x * kv.x + hh.y * kv.y + hh.z * kv.z + hh.w * kv.w;
+            }
+          }
+          dot2 += __shfl_xor(dot2, 1, 64);
+          dot2 += __shfl_xor(dot2, 2, 64);
+          dot2 += __shfl_xor(dot2, 4, 64);
+          if (kg == 0) esc[t2] = dot2 + s0m[t2];
+        }
         ds_mark(cE, wave, i + 1);
         if (!ds_wait4(cE, i + 1, abort_flag, lds_limit, 5 | (i << 8))) break;
         // every lane evaluates the chunk's softmax statistics itself from broadcast LDS reads of the <= 32 scores (no cross-lane
@@ -216,6 +241,13 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           const float4 e4 = *reinterpret_cast<const float4*>(esc + 4 * t4);
           m = fmaxf(fmaxf(m, fmaxf(e4.x, e4.y)), fmaxf(e4.z, e4.w));
         }
+        if (LONG && nt > DS_MAXTC) {                              // (T' > 256: the second half of the chunk; wave-uniform)
+#pragma unroll
+          for (int t4 = DS_MAXTC / 4; t4 < DS_MAXTC2 / 4; ++t4) {
+            const float4 e4 = *reinterpret_cast<const float4*>(esc + 4 * t4);
+            m = fmaxf(fmaxf(m, fmaxf(e4.x, e4.y)), fmaxf(e4.z, e4.w));
+          }
+        }
         float l = 0.f;
 #pragma unroll
         for (int t4 = 0; t4 < DS_MAXTC / 4; ++t4) {
@@ -223,8 +255,16 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           l += (e4.x == -INFINITY ? 0.f : fast_exp_(e4.x - m)) + (e4.y == -INFINITY ? 0.f : fast_exp_(e4.y - m)) +
                (e4.z == -INFINITY ? 0.f : fast_exp_(e4.z - m)) + (e4.w == -INFINITY ? 0.f : fast_exp_(e4.w - m));
         }
-        float* ptw_ = pt + wave * 32;
-        if (lane < 32) {
+        if (LONG && nt > DS_MAXTC) {
+#pragma unroll
+          for (int t4 = DS_MAXTC / 4; t4 < DS_MAXTC2 / 4; ++t4) {
+            const float4 e4 = *reinterpret_cast<const float4*>(esc + 4 * t4);
+            l += (e4.x == -INFINITY ? 0.f : fast_exp_(e4.x - m)) + (e4.y == -INFINITY ? 0.f : fast_exp_(e4.y - m)) +
+                 (e4.z == -INFINITY ? 0.f : fast_exp_(e4.z - m)) + (e4.w == -INFINITY ? 0.f : fast_exp_(e4.w - m));
+          }
+        }
+        float* ptw_ = pt + wave * DS_MAXTC2;
+        {
           const float e1 = esc[lane];
           ptw_[lane] = e1 == -INFINITY ? 0.f : fast_exp_(e1 - m);      // frames beyond the chunk carry -inf
         }
@@ -234,8 +274,15 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         const int f0 = 2 * tid;
         if (f0 < D) {
 #pragma unroll 8
-          for (int t2 = 0; t2 < nt; ++t2) {
+          for (int t2 = 0; t2 < (LONG ? (nt < DS_MAXTC ? nt : DS_MAXTC) : nt); ++t2) {      // (a plain `nt` bound where it can be: the min() costs the common instance 32 bytes of spills)
             const float2 ev2 = *reinterpret_cast<const float2*>(enc_s + t2 * ENLD + f0);
+            const float pw = ptw_[t2];
+            c0 = fmaf(pw, ev2.x, c0);
+            c1 = fmaf(pw, ev2.y, c1);
+          }
+#pragma unroll 8
+          for (int t2 = DS_MAXTC; LONG && t2 < nt; ++t2) {          // (T' > 256 only) the streamed frames: one coalesced 8-byte load per thread and frame
+            const float2 ev2 = *reinterpret_cast<const float2*>(a.enc + ((long)ab * T2 + t_lo + t2) * D + f0);
             const float pw = ptw_[t2];
             c0 = fmaf(pw, ev2.x, c0);
             c1 = fmaf(pw, ev2.y, c1);
@@ -285,7 +332,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           }
           const float inv = 1.f / L;
           if (lane < FS) cslice[lane] = val * inv;
-          if (lane < 32) pn[lane] = pt[lane] * alpha_own * inv;
+          pn[lane] = pt[lane] * alpha_own * inv;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (lane == 0) *cC = i + 1;
         }
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
             keep = 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const uint32_t idx = (uint32_t)((long)(tile * 16 + li) * (Hd + D) + Hd + 16 * (wave + 4 * k) + 4 * lq);
+              const uint32_t idx = (uint32_t)((long)(b0_ + tile * 16 + li) * (Hd + D) + Hd + 16 * (wave + 4 * k) + 4 * lq);
 #pragma unroll
               for (int e = 0; e < 4; ++e) keep |= (asr_rng_u32(key, idx + e) >= thresh ? 1u : 0u) << (4 * k + e);
             }
@@ -348,13 +395,13 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           use[4] = wave == 0 && lane < 16;                       // c0 of the owned pairs
           o5[4] = use[4] ? (unsigned)(((a.o_c0 - a.o_h0) + (((long)tile * Q + q) * 16 + lane) * 4) * 4) : 0u;
           const int brow = tile * 16 + li;
-          const bool rowm = brow < B ? a.tokmask[(long)i * B + brow] != 0 : false;
+          const bool rowm = brow < B ? a.tokmask[(long)i * Bs_ + brow] != 0 : false;
           unsigned keep = rowm ? 0xFFFFu : 0u;                   // one keep-bit per operand (bit 4k + e)
           if (rowm && a.rate > 0.f) {
             keep = 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const uint32_t idx = (uint32_t)((long)brow * Hd + 16 * (wave + 4 * k) + 4 * lq);
+              const uint32_t idx = (uint32_t)((long)(b0_ + brow) * Hd + 16 * (wave + 4 * k) + 4 * lq);
 #pragma unroll
               for (int e = 0; e < 4; ++e) keep |= (asr_rng_u32(key, idx + e) >= thresh ? 1u : 0u) << (4 * k + e);
             }
@@ -404,19 +451,24 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
       bool m = true;
       float pre[4] = {bias[0], bias[1], bias[2], bias[3]};
       if (live) {
-        m = a.tokmask[(long)i * B + brow] != 0;
+        m = a.tokmask[(long)i * Bs_ + brow] != 0;
         if (layer == 0) {
-          const float* pr = a.pre0 + ((long)i * B + brow) * 4 * Hd + j;
+          const float* pr = a.pre0 + ((long)i * Bs_ + brow) * 4 * Hd + j;
 #pragma unroll
           for (int g = 0; g < 4; ++g) pre[g] = pr[(long)g * Hd];
         }
       }
       // ---- the chunk's partial: {m, l}, ctx_c ----
+      // ONE wait per step for this wave's stores: it retires every sentinel of the previous step before any publish of this one (a
+      // slot re-armed at step i is rewritten at step i + 2 and polled again only by readers that have consumed this wave's step
+      // i + 1 pieces).  Rounds 1-2 also waited in front of the slice and the cell publish - i.e. for the write-through
+      // acknowledgement of the stores issued a moment earlier in the same step, a fabric round trip each on the step's critical chain
+      // (placed while the gather waves are still busy with the attention stage: the wait is off the chain)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!ds_wait4(cA, i + 1, abort_flag, lds_limit, 7 | (i << 8))) break;
       if (attn) {
         const int npieces = 1 + (D >> 2);
         const long base = a.o_part + ((long)ab * DS_NC + ac) * (4 + D);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int pc = lane; pc < npieces; pc += 64) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(pbuf + 4 * pc);
           __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)((slot_cur + base + 4 * pc) * 4), 0, 16);
@@ -426,15 +478,15 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
       // ---- the combined context slice ----
       if (attn) {
         if (!ds_wait(cC, i + 1, abort_flag, lds_limit, 8 | (i << 8))) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");                   // (compiler barrier only: keeps the slice's LDS reads behind the wait)
         if (lane < (FS >> 2)) {
           const u32x4 v = *reinterpret_cast<const u32x4*>(cslice + 4 * lane);
           const long off = a.o_ctx + (((long)atile * (D >> 2) + (FS >> 2) * ac + lane) * 16 + arow) * 4;
           __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)((slot_cur + off) * 4), 0, 16);
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + off) * 4), 0, 16);
         }
-        if (lane < FS) a.ctx[((long)i * B + ab) * D + FS * ac + lane] = cslice[lane];
-        if (lane < nt) a.p[((long)i * B + ab) * T2 + t_lo + lane] = pn[lane];
+        if (lane < FS) a.ctx[((long)i * Bs_ + ab) * D + FS * ac + lane] = cslice[lane];
+        if (lane < nt) a.p[((long)i * Bs_ + ab) * T2 + t_lo + lane] = pn[lane];
       }
       // ---- the cell ----
       if (!ds_wait4(cD, i + 1, abort_flag, lds_limit, 9 | (i << 8))) break;
@@ -452,7 +504,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         f32x4 ph, pc4;
         ph.x = hnew; ph.y = __shfl_down(hnew, 1, 64); ph.z = __shfl_down(hnew, 2, 64); ph.w = __shfl_down(hnew, 3, 64);
         pc4.x = cnew; pc4.y = __shfl_down(cnew, 1, 64); pc4.z = __shfl_down(cnew, 2, 64); pc4.w = __shfl_down(cnew, 3, 64);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
         if (u == 0) {
           const long blk = (((long)tile * Q + q) * 16 + bi) * 4;
           const long oh = layer == 0 ? a.o_h0 : a.o_h1, oc = layer == 0 ? a.o_c0 : a.o_c1;
@@ -462,7 +514,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + oc + blk) * 4), 0, 16);
         }
         if (live) {
-          const long row = (long)i * B + brow;
+          const long row = (long)i * Bs_ + brow;
           float* svp = (layer == 0 ? a.saved0 : a.saved1) + row * 4 * Hd + j;
 #pragma unroll
           for (int g = 0; g < 4; ++g) svp[(long)g * Hd] = sv[g];
@@ -471,8 +523,8 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
             a.h0[row * Hd + j] = hnew;
             a.c0[row * Hd + j] = cnew;
           } else {
-            a.hin[((long)(i + 1) * B + brow) * Hd + j] = hnew;
-            a.cin[((long)(i + 1) * B + brow) * Hd + j] = cnew;
+            a.hin[((long)(i + 1) * Bs_ + brow) * Hd + j] = hnew;
+            a.cin[((long)(i + 1) * Bs_ + brow) * Hd + j] = cnew;
           }
         }
       }
@@ -491,7 +543,8 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
 }
 
 static size_t ds_lds_bytes(int Hd, int D) {
-  const size_t floats = (size_t)DS_MAXTC * (Hd + 4) + (size_t)DS_MAXTC * (D + 4) + 32 + 4 * 256 + 32 + 4 * 32 + (4 + 512) + 8 * 68 + 64 + 32 + 2 * 4 * 272 + 64 + 64 + 32;
+  const size_t floats = (size_t)DS_MAXTC * (Hd + 4) + (size_t)DS_MAXTC * (D + 4) + DS_MAXTC2 + 4 * 256 + DS_MAXTC2 + 4 * DS_MAXTC2 + (4 + 512) + 8 * 68 + 64 +
+                        DS_MAXTC2 + 2 * 4 * 272 + 64 + 64 + 32;
   return floats * sizeof(float);
 }
 
@@ -504,18 +557,20 @@ static void ds_layout(int Hd, int D, long* o_h1, long* o_c1, long* o_h0, long* o
 }
 
 extern "C" int asr_decoder_sweep_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D) {
-  if (rnn_type != 0 || num_layers != 2 || B <= 0 || B > 32 || U < 1 || T2 < 1 || T2 > DS_NC * DS_MAXTC) return 0;
+  // B <= 64: batches of more than 32 rows run as two launches of <= 32 rows (asr_decoder_sweep_fwd does that itself); T' <= 512:
+  // chunks of up to 64 frames, the first 32 of each resident in LDS, the rest streamed (libri_config.yml max_audio_length 2048 frames: T' = 511)
+  if (rnn_type != 0 || num_layers != 2 || B <= 0 || B > 64 || U < 1 || T2 < 1 || T2 > DS_NC * DS_MAXTC2) return 0;
   if (Hd <= 0 || Hd % 16 != 0 || Hd > 256 || D <= 0 || D % 32 != 0 || D > 512) return 0;
   // 256 workgroups that wait for each other, ~100 KB of LDS each: one per compute unit, all resident at once.  The occupancy answer
   // is a query, not a reservation (single tenant assumed: another process holding LDS on one CU stalls the grid until it leaves or
   // the spin limit reports it - sweep_common.h says which); a device that cannot hold the grid even when empty is refused here
   static long cap = 0;
   if (cap == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, cus = 0, per = 0;
     cap = -1;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), 320, ds_lds_bytes(256, 512)) == hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), 320, ds_lds_bytes(256, 512)) == hipSuccess)
       cap = (long)per * cus;
     (void)hipGetLastError();
   }
@@ -558,17 +613,33 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_DELAY")) : 8;   // negative: timing experiment, gathers do not wait
-  {
+  const size_t smem = ds_lds_bytes(s->Hd, s->D);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  // one launch per 32 batch rows (the grid is 32 rows x 8 chunks of attention and 2 batch tiles of cells): the passes are independent
+  // chains over the same U steps, each as long as one launch - twice the time for B = 64, against 9 launches per step on the fallback
+  a.Bs = s->B;
+  for (int b0 = 0; b0 < s->B; b0 += 32) {
+    const long T2 = s->T2, Hd = s->Hd, D = s->D;
+    a.B = s->B - b0 < 32 ? s->B - b0 : 32; a.b0 = b0;
+    a.Kq = s->Kq + b0 * T2 * Hd; a.enc = s->enc + b0 * T2 * D; a.s0 = s->s0 ? s->s0 + b0 * T2 : nullptr; a.mask = s->mask + b0 * T2;
+    a.h_init = s->h_init + b0 * Hd; a.c_init = s->c_init + b0 * Hd;
+    a.pre0 = s->pre0 + b0 * 4 * Hd; a.tokmask = s->tokmask + b0;
+    a.p = s->p + b0 * T2; a.ctx = s->ctx + b0 * D; a.hin = s->hin + b0 * Hd; a.cin = s->cin + b0 * Hd;
+    a.y0 = s->y0 + b0 * Hd; a.saved0 = s->saved0 + b0 * 4 * Hd; a.h0 = s->h0 + b0 * Hd; a.c0 = s->c0 + b0 * Hd;
+    a.y1 = s->y1 + b0 * Hd; a.saved1 = s->saved1 + b0 * 4 * Hd;
     const size_t n = (size_t)xfloats;
     hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st,
                        reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
     (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
     ASR_LAUNCH_CHECK();
+    if (a.TC > DS_MAXTC || a.Bs != a.B || a.b0 != 0) hipLaunchKernelGGL(decoder_sweep_fwd_kernel<true>, dim3(256), dim3(320), smem, st, a);
+    else hipLaunchKernelGGL(decoder_sweep_fwd_kernel<false>, dim3(256), dim3(320), smem, st, a);
+    ASR_LAUNCH_CHECK();
   }
-  const size_t smem = ds_lds_bytes(s->Hd, s->D);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(decoder_sweep_fwd_kernel, dim3(256), dim3(320), smem, st, a);
-  ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

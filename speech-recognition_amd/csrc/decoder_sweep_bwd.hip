@@ -29,6 +29,7 @@
 
 struct DbArgs {
   int B, U, T2, Hd, D, TC, G, FC, FS;     // FC = D / G context features per square column, FS = D / 8 features per chunk (saved dctx slice)
+  int Bs, b0;                               // row stride of the step-major tensors / first batch row of this launch (batches > 32 run in passes)
   const float* Kq; const float* enc;
   const float* p; const float* ctx;
   const float* saved0; const float* saved1;
@@ -158,9 +159,9 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
   float* dcx = ctxT + 16 * 68;                         // [256][4] context-gradient partial sums
   float* dcv_s = dcx + 1024;                           // [512] context gradient of the row
   float* dotw = dcv_s + 512;                           // [8]
-  float* des = dotw + 8;                               // [32] score gradients of the chunk
-  float* ps = des + 32;                                // [32] attention weights of the chunk
-  float* dqs = ps + 32;                                // [256] partial query gradient
+  float* des = dotw + 8;                               // [64] score gradients of the chunk
+  float* ps = des + DS_MAXTC2;                         // [64] attention weights of the chunk
+  float* dqs = ps + DS_MAXTC2;                         // [256] partial query gradient
   int* flags = reinterpret_cast<int*>(dqs + 256);      // [64]
   volatile int* abort_flag = flags;
   volatile int *cG = flags + 4, *cO = flags + 8, *cS = flags + 12, *cA1 = flags + 16, *cA2 = flags + 20, *cA3 = flags + 24, *cA4 = flags + 28;
@@ -169,14 +170,15 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
   swd_setprio(a.prio);
 
   // ---- resident attention operands ----
+  const int ntr = min(nt, DS_MAXTC);                    // frames resident in LDS; frames [ntr, nt) are read from memory every step (T' > 256)
+  const float* kqg = a.Kq + ((long)(attn ? ab : 0) * T2 + t_lo) * Hd;
+  const float* eng = a.enc + ((long)(attn ? ab : 0) * T2 + t_lo) * D;
   if (attn) {
-    const float* kqg = a.Kq + ((long)ab * T2 + t_lo) * Hd;
-    for (int i = tid; i < nt * (Hd >> 2); i += 512) {
+    for (int i = tid; i < ntr * (Hd >> 2); i += 512) {
       const int t = i / (Hd >> 2), k4 = i % (Hd >> 2);
       *reinterpret_cast<float4*>(kq_s + t * KQLD + 4 * k4) = *reinterpret_cast<const float4*>(kqg + (long)t * Hd + 4 * k4);
     }
-    const float* eng = a.enc + ((long)ab * T2 + t_lo) * D;
-    for (int i = tid; i < nt * (D >> 2); i += 512) {
+    for (int i = tid; i < ntr * (D >> 2); i += 512) {
       const int t = i / (D >> 2), k4 = i % (D >> 2);
       *reinterpret_cast<float4*>(enc_s + t * ENLD + 4 * k4) = *reinterpret_cast<const float4*>(eng + (long)t * D + 4 * k4);
     }
@@ -213,14 +215,14 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
         o[r].m = true; o[r].cp = 0.f; o[r].co = 0.f; o[r].dy = 0.f;
         o[r].sv[0] = o[r].sv[1] = o[r].sv[2] = o[r].sv[3] = 0.f;
         if (live[r] && p < U) {
-          const long row = (long)i * B + brow[r];
+          const long row = (long)i * a.Bs + brow[r];
           o[r].m = a.tokmask[row] != 0;
           const float* sv = (layer == 0 ? a.saved0 : a.saved1) + row * 4 * Hd + j;
 #pragma unroll
           for (int g = 0; g < 4; ++g) o[r].sv[g] = sv[(long)g * Hd];
           if (layer == 1) {
             o[r].dy = a.dy1[row * a.dy1_ld + j];
-            o[r].co = a.cin[((long)(i + 1) * B + brow[r]) * Hd + j];     // c1(i)
+            o[r].co = a.cin[((long)(i + 1) * a.Bs + brow[r]) * Hd + j];  // c1(i)
             o[r].cp = a.c0[row * Hd + j];                               // layer 1 starts from layer 0's state
           } else {
             o[r].co = a.c0[row * Hd + j];
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
     auto fetch_attn = [&](int p) {
       const int i = U - 1 - p;
       if (attn && p < U) {
-        const long row = (long)i * B + ab;
+        const long row = (long)i * a.Bs + ab;
         if (tid < nt) pre_p = a.p[row * T2 + t_lo + tid];
         if (2 * tid < D) pre_c = *reinterpret_cast<const float2*>(a.ctx + row * D + 2 * tid);
       }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
       if (p == U) break;
       // ------------------------------------------------------------------------------------------ attention role
       if (attn) {
-        if (tid < 32) ps[tid] = tid < nt ? pre_p : 0.f;
+        if (tid < DS_MAXTC2) ps[tid] = tid < nt ? pre_p : 0.f;
         const float2 cx = pre_c;
         {
           const int QD = D >> 2, SH = 256 / QD;           // piece = (sender, feature quad); SH senders in flight per pass
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
             }
             if (a.rate > 0.f) {
               const AsrRngKey key = asr_rng_key(seedv, a.stream0 + a.stream_step * (uint32_t)i + 2u);
-              const uint32_t idx = (uint32_t)((long)ab * (Hd + D) + Hd + f0);
+              const uint32_t idx = (uint32_t)((long)(a.b0 + ab) * (Hd + D) + Hd + f0);
               d0 *= asr_drop_mult(key, idx, thresh, scale);
               d1 *= asr_drop_mult(key, idx + 1, thresh, scale);
             }
@@ -427,12 +429,30 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
           dp += __shfl_xor(dp, 2, 64);
           dp += __shfl_xor(dp, 4, 64);
           if (kg == 0) des[t] = t < nt ? ps[t] * (dp - dot) : 0.f;
+          if (nt > DS_MAXTC) {                              // the frames the LDS does not hold: their encoder rows from memory
+            const int t2 = DS_MAXTC + t;
+            float dp2 = 0.f;
+            if (t2 < nt) {
+              const float* er = eng + (long)t2 * D;
+              for (int k4 = kg; k4 < (D >> 2); k4 += 8) {
+                const float4 ev = *reinterpret_cast<const float4*>(er + 4 * k4);
+                const float4 dv = *reinterpret_cast<const float4*>(dcv_s + 4 * k4);
+                dp2 += dv.x * ev.x + dv.y * ev.y + dv.z * ev.z + dv.w * ev.w;
+              }
+            }
+            dp2 += __shfl_xor(dp2, 1, 64);
+            dp2 += __shfl_xor(dp2, 2, 64);
+            dp2 += __shfl_xor(dp2, 4, 64);
+            if (kg == 0) des[t2] = t2 < nt ? ps[t2] * (dp2 - dot) : 0.f;
+          }
         }
         ds_mark(cA3, wv, p + 1);
         if (!ds_wait4(cA3, p + 1, abort_flag, lds_limit, 8 | (p << 8))) break;
         if (tid < Hd) {
           float dq = 0.f;
-          for (int t = 0; t < nt; ++t) dq = fmaf(des[t], kq_s[t * KQLD + tid], dq);
+          for (int t = 0; t < ntr; ++t) dq = fmaf(des[t], kq_s[t * KQLD + tid], dq);
+#pragma unroll 8
+          for (int t = ntr; t < nt; ++t) dq = fmaf(des[t], kqg[(long)t * Hd + tid], dq);     // (T' > 256) streamed keys, coalesced over tid
           dqs[tid] = dq;
         }
         ds_mark(cA4, wv, p + 1);
@@ -502,16 +522,6 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
             if (jb < njobs) *reinterpret_cast<f32x4*>(sp + ((long)((kp - 1) * NT + nt_) * NJ + jb) * 256 + lane * 4) = acc[jb];
         }
         ds_mark(cS, sw, p + 1);
-        if (writer) {
-          float* dso = (layer == 0 ? a.ds0 : a.ds1);
-#pragma unroll
-          for (int e = 0; e < NT; ++e) {
-            const int qd = sw * 64 + lane + 256 * e, row = qd / (NL / 4), qir = qd % (NL / 4);
-            const int lab = 4 * qir, g = lab / KU, cu = lab % KU;
-            const int br = tile * 16 + row;
-            if (br < B) *reinterpret_cast<f32x4*>(dso + ((long)i * B + br) * 4 * Hd + (long)g * Hd + gi * KU + cu) = dsv[e];
-          }
-        }
         if (kp == 0) {
           if (KP > 1) {
             if (!ds_wait4(cS, p + 1, abort_flag, lds_limit, 11 | (p << 8))) break;
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
               const AsrRngKey key = asr_rng_key(seedv, a.stream0 + a.stream_step * (uint32_t)i + 3u);
               const int k = gj * KU + 16 * nt_ + li;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dm[r] = asr_drop_mult(key, (uint32_t)((long)(tile * 16 + 4 * lq + r) * Hd + k), thresh, scale);
+              for (int r = 0; r < 4; ++r) dm[r] = asr_drop_mult(key, (uint32_t)((long)(a.b0 + tile * 16 + 4 * lq + r) * Hd + k), thresh, scale);
             }
             vh += dm * acc[1];
           }
@@ -574,20 +584,33 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
             }
           }
         }
+        // the layer's ds to memory AFTER the publish: in front of it these stores (to lines nobody has touched yet) would have to be
+        // acknowledged before the publish's `s_waitcnt vmcnt(0)` lets the block out - a memory round trip on the critical chain of
+        // every step (rounds 1-2 had them there); here they are retired by the next step's wait, a whole exchange round later
+        if (writer) {
+          float* dso = (layer == 0 ? a.ds0 : a.ds1);
+#pragma unroll
+          for (int e = 0; e < NT; ++e) {
+            const int qd = sw * 64 + lane + 256 * e, row = qd / (NL / 4), qir = qd % (NL / 4);
+            const int lab = 4 * qir, g = lab / KU, cu = lab % KU;
+            const int br = tile * 16 + row;
+            if (br < B) *reinterpret_cast<f32x4*>(dso + ((long)i * a.Bs + br) * 4 * Hd + (long)g * Hd + gi * KU + cu) = dsv[e];
+          }
+        }
       }
       if (attn && sw == 3) {
         if (!ds_wait4(cA4, p + 1, abort_flag, lds_limit, 12 | (p << 8))) break;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f};
         if (lane < (Hd >> 2)) qv = *reinterpret_cast<const f32x4*>(dqs + 4 * lane);
         const float dcv = lane < FS ? dcv_s[FS * ac + lane] : 0.f;
-        const float dev = lane < 32 ? des[lane] : 0.f;
+        const float dev = des[lane];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
         if (lane < (Hd >> 2)) {
           const long o = a.o_q + ((long)ab * DS_NC + ac) * Hd + 4 * lane;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qv), rsrc, (int)((slot_cur + o) * 4), 0, 16);
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + o) * 4), 0, 16);
         }
-        const long row = (long)i * B + ab;
+        const long row = (long)i * a.Bs + ab;
         if (lane < FS) a.dctx[row * D + FS * ac + lane] = dcv;
         if (lane < nt) a.de[row * T2 + t_lo + lane] = dev;
       }
@@ -623,7 +646,7 @@ static bool db_geometry(int Hd, int D, int* nt, int* G) {
 static size_t db_lds_bytes(int Hd, int D, int nt) {
   const int KU = 16 * nt, NL = 4 * KU, KP = 4 / nt, NPOS = 64 * nt, NJ = 1 + (nt == 2 ? 2 : 4);
   const size_t floats = (size_t)DS_MAXTC * (Hd + 4) + (size_t)DS_MAXTC * (D + 4) + 1024 + 1024 + 16 * (NL + 4) + 2 * NPOS * 4 + (size_t)(KP - 1) * nt * NJ * 256 +
-                        16 * 68 + 1024 + 512 + 8 + 32 + 32 + 256 + 64;
+                        16 * 68 + 1024 + 512 + 8 + DS_MAXTC2 + DS_MAXTC2 + 256 + 64;
   return floats * sizeof(float);
 }
 
@@ -637,7 +660,7 @@ static void db_layout(int Hd, int D, int nt, int G, long* o_p1, long* o_c1, long
 }
 
 extern "C" int asr_decoder_sweep_bwd_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D) {
-  if (rnn_type != 0 || num_layers != 2 || B <= 0 || B > 32 || U < 1 || T2 < 1 || T2 > DS_NC * DS_MAXTC) return 0;
+  if (rnn_type != 0 || num_layers != 2 || B <= 0 || B > 64 || U < 1 || T2 < 1 || T2 > DS_NC * DS_MAXTC2) return 0;   // (see asr_decoder_sweep_supported)
   int nt, G;
   if (!db_geometry(Hd, D, &nt, &G)) return 0;
   if (db_lds_bytes(Hd, D, nt) > 160 * 1024) return 0;
@@ -684,13 +707,6 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_BWD_DELAY")) : 4;
-  {
-    const size_t n = (size_t)xfloats;
-    hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
-                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
-    (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
-    ASR_LAUNCH_CHECK();
-  }
   const size_t smem = db_lds_bytes(s->Hd, s->D, nt);
   static bool attr = false;
   if (!attr) {
@@ -698,8 +714,22 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  if (nt == 1) hipLaunchKernelGGL(decoder_sweep_bwd_kernel<1>, dim3(256), dim3(512), smem, st, a);
-  else hipLaunchKernelGGL(decoder_sweep_bwd_kernel<2>, dim3(256), dim3(512), smem, st, a);
-  ASR_LAUNCH_CHECK();
+  a.Bs = s->B;
+  for (int b0 = 0; b0 < s->B; b0 += 32) {                 // one launch per 32 batch rows (see asr_decoder_sweep_fwd)
+    const long T2 = s->T2, Hd = s->Hd, D = s->D;
+    a.B = s->B - b0 < 32 ? s->B - b0 : 32; a.b0 = b0;
+    a.Kq = s->Kq + b0 * T2 * Hd; a.enc = s->enc + b0 * T2 * D; a.p = s->p + b0 * T2; a.ctx = s->ctx + b0 * D;
+    a.saved0 = s->saved0 + b0 * 4 * Hd; a.saved1 = s->saved1 + b0 * 4 * Hd; a.ds0 = s->ds0 + b0 * 4 * Hd; a.ds1 = s->ds1 + b0 * 4 * Hd;
+    a.cin = s->cin + b0 * Hd; a.c0 = s->c0 + b0 * Hd; a.tokmask = s->tokmask + b0; a.dy1 = s->dy1 + b0 * s->dy1_ld;
+    a.de = s->de + b0 * T2; a.dctx = s->dctx + b0 * D; a.dhs = s->dh_init + b0 * Hd; a.dc = s->dc_init + b0 * Hd;
+    const size_t n = (size_t)xfloats;
+    hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
+                       reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
+    (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
+    ASR_LAUNCH_CHECK();
+    if (nt == 1) hipLaunchKernelGGL(decoder_sweep_bwd_kernel<1>, dim3(256), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL(decoder_sweep_bwd_kernel<2>, dim3(256), dim3(512), smem, st, a);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }

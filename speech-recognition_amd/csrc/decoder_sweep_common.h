@@ -9,7 +9,8 @@
 #define DS_SLOTS 4
 #define DS_SENT 0x7FC0DEADu
 #define DS_NC 8                    // time chunks per batch row
-#define DS_MAXTC 32                // encoder frames per chunk
+#define DS_MAXTC 32                // encoder frames of a chunk RESIDENT in LDS
+#define DS_MAXTC2 64               // encoder frames per chunk: the ones beyond DS_MAXTC are streamed from L2 / Infinity Cache every step
 #define DS_MAXHB 4                 // K blocks of h per gather wave: Hd <= 256
 #define DS_MAXCB 8                 // K blocks of the context per gather wave: D <= 512
 

@@ -71,8 +71,53 @@ def test_las_small_yml_headline_step_batch_32_against_the_oracle():
     RC._check_grads(model, leaves, 5e-3, RC.LAS_NAMED)
 
 
+def test_las_small_yml_15_second_clips_run_both_decoder_sweeps():
+    """libri_config.yml allows 2048 frames (T' = 511); a 15 s batch (T = 1499, T' = 374) used to fall off the decoder sweeps (T' <= 256)
+    onto nine launches per decoder step.  las_small.yml at B = 32, 15 s, U = 24: both decoder sweeps run (asserted), and loss and
+    every gradient equal the per-step kernels' on the same batch and masks (3e-5; the oracle checks of the streamed-frame path are
+    test_decoder_sweeps_against_the_oracle_directly[40-1400-...] and the T' = 374 cases of tests/test_real_configs_gpu.py)."""
+    from speech_recognition_amd import ops
+    from speech_recognition_amd.configs import get_model_config
+    from speech_recognition_amd.models import las as las_mod
+    B = 32
+    mc = RC._yaml("las_small.yml")
+    _, plan = RC._frontend()
+    seed = 515
+    audio, n = RC._audio(B, 15.0, short={4: 9.0, 20: 12.5})
+    toks = RC._tokens(B, 25, mc["vocab_size"], ragged={7: 11})
+    feats = plan(torch.from_numpy(audio).cuda(), torch.from_numpy(n).cuda(), plan.num_frames(audio.shape[1]),
+                 seed=torch.tensor([seed], dtype=torch.int32, device="cuda"))
+    t = torch.from_numpy(toks)
+    res = {}
+    for sweeps in (True, False):
+        las_mod.DECODER_SWEEP = las_mod.DECODER_SWEEP_BWD = sweeps
+        try:
+            model = get_model_config(os.path.join(RC.CONFIGS, "las_small.yml")).create_model(seed=7)
+            model.build(80, 3)
+            model.state[1] = seed
+            ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+            assert (ws.T2, ws.U) == (374, 24)
+            model.set_targets(ws, t.cuda(), labels)
+            ops.fill(model.store.grad, 0.0)
+            model.forward_ws(ws, feats, True, True)
+            model.loss_and_grad(ws, labels)
+            model.backward_ws(ws, feats)
+            torch.cuda.synchronize()
+            assert getattr(ws, "_sweep_ok", False) == sweeps and getattr(ws, "_sweep_bwd_ok", False) == sweeps, "15 s clips must stay on the decoder sweeps"
+            if sweeps:
+                assert not ops.decoder_sweep_error(ws.dsweep_ws) and not ops.decoder_sweep_error(ws.dsweep_bwd_ws)
+            res[sweeps] = (float(ws.stats[0]), {k: v.clone() for k, v in model.store.grads().items()})
+        finally:
+            las_mod.DECODER_SWEEP = las_mod.DECODER_SWEEP_BWD = True
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1.0, abs(res[False][0]))
+    for k, ref in res[False][1].items():
+        if float(ref.abs().max()) > 1e-7:                # (biases in front of BatchNorm / inside the softmax have zero gradient up to rounding)
+            assert_close(res[True][1][k], ref, 5e-5, k)
+
+
 # ---------------------------------------------------------------------------------------------- decoder sweeps vs the oracle's own tensors
-@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(32, 999, 12, 256, 256, 0.15), (19, 70, 6, 32, 32, 0.0)])
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(32, 999, 12, 256, 256, 0.15), (19, 70, 6, 32, 32, 0.0),
+                                                 (40, 1400, 3, 64, 64, 0.1)])        # B > 32 (two passes) and T' = 349 > 256 (streamed frames)
 def test_decoder_sweeps_against_the_oracle_directly(B, T, U, He, Hd, dropout):
     """decoder_sweep_fwd / decoder_sweep_bwd outputs against oracle.las aux tensors: p, ctx, per-layer h / c / y forward; de (scores),
     dctx, d(initial h, c) backward.  1e-4 of the largest entry forward (f32 softmax over 249 frames, 12 chained steps), 2e-4

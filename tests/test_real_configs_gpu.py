@@ -368,7 +368,9 @@ def test_las_whole_model_gradients_through_persistent_kernels(rt):
         assert_close(v, aux["bn_updates"][n], 1e-4, n)
 
 
-@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (32, 200, 9, 64, 48, 0.0), (5, 40, 3, 16, 16, 0.2), (32, 999, 12, 256, 256, 0.15)])
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (32, 200, 9, 64, 48, 0.0), (5, 40, 3, 16, 16, 0.2), (32, 999, 12, 256, 256, 0.15),
+                                                 (32, 1499, 4, 256, 256, 0.15),      # 15 s clips: T' = 374 > 256, chunks of 47 frames (32 resident + streamed)
+                                                 (47, 1250, 3, 64, 64, 0.1)])       # B > 32: two passes of <= 32 rows; T' = 311
 def test_decoder_sweep_equals_per_step_kernels(B, T, U, He, Hd, dropout):
     """The one-launch decoder sweep (all U steps of attention + two LSTM cells, decoder_sweep.hip) against the per-step kernels it
     replaces, on the same model and batch: probabilities, contexts, gate activations, states and logits - equal to f32 rounding
@@ -404,7 +406,8 @@ def test_decoder_sweep_equals_per_step_kernels(B, T, U, He, Hd, dropout):
         assert_close(outs[True][k], ref, 1e-5, k)
 
 
-@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (5, 40, 3, 16, 16, 0.2), (32, 120, 7, 64, 128, 0.0), (32, 999, 12, 256, 256, 0.15)])
+@pytest.mark.parametrize("B,T,U,He,Hd,dropout", [(19, 70, 6, 32, 32, 0.15), (5, 40, 3, 16, 16, 0.2), (32, 120, 7, 64, 128, 0.0), (32, 999, 12, 256, 256, 0.15),
+                                                 (32, 1499, 4, 256, 256, 0.15), (47, 1250, 3, 64, 64, 0.1)])    # T' > 256 / B > 32 (see the forward test)
 def test_decoder_sweep_bwd_equals_per_step_kernels(B, T, U, He, Hd, dropout):
     """The one-launch BACKWARD decoder sweep (decoder_sweep_bwd.hip) against the per-step kernels it replaces (two cell-backward
     launches, the context gradient and the attention backward per step), same model, batch and dropout masks: score / context /
