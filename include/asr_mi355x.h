@@ -143,6 +143,11 @@ int asr_fill_f32(float* p, long n, float value, void* stream);
 int asr_frame_mask(const float* x, int B, int T, int FC, int group, int Tout, uint8_t* out, void* stream);
 /* out[c] += sum_r A[r][c]  (bias gradients; atomic) */
 int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream);
+/* The one-column products of the hoisted attention (las.py:46-59: query_weight bias): out[c] += sum_r w[r] A[r][c] (d bq = K^T ds0),
+ * y[r] = A[r][:] . x (s0 = K bq), C[r][c] += u[r] v[c] (the ds0 (x) bq term of dK) - memory-bound kernels instead of N = 1 / K = 1 GEMMs. */
+int asr_colsum_weighted(const float* A, int M, int N, long lda, const float* w, float* out, void* stream);
+int asr_rowdot(const float* A, int M, int K, long lda, const float* x, float* y, void* stream);
+int asr_rank1_add(float* C, int M, int N, long ldc, const float* u, const float* v, void* stream);
 /* BatchNormalization(axis=-1) (+ fused ReLU) over x [M, C] (las.py:170,193; deepspeech2.py:112,118).
  * training: biased batch statistics over all M rows, mean/rstd saved, moving stats updated with
  * `momentum`; inference: moving statistics.  stats_ws: 2*C doubles of scratch. */
@@ -170,6 +175,9 @@ int asr_dropout_rows(const float* x, long ldx, float* y, long ldy, int R, int K,
 int asr_dropout_flat(float* x, long n, const uint32_t* seed, uint32_t stream_id, float rate, void* stream);
 /* out[i] = mult(stream_id, i): the [B, D] table of a Keras RNN input dropout (las.py:94,102) */
 int asr_dropout_table(float* out, long n, const uint32_t* seed, uint32_t stream_id, float rate, void* stream);
+/* several such tables in one launch (all BiRNN layers of a step draw from the same seed) */
+int asr_dropout_tables(int ntables, float* const* outs, const long* ns, const uint32_t* stream_ids, const float* rates, const uint32_t* seed,
+                       void* stream);
 /* Embedding (las.py:258,278): backward == 0: x[r,:] = E[tok[r],:] * drop1 * drop2;
  * backward != 0: dE[tok[r],:] += dx[r,:] * drop1 * drop2 (atomic).  R rows, Hd columns. */
 int asr_embedding(int backward, float* E_or_dE, const int32_t* tok, int R, int Hd, int V, float* x_or_dx, long ld,
@@ -251,6 +259,13 @@ int asr_rnn_geometry(int rnn_type, int H, int nseg, const int* K, asr_rnn_geom* 
  * fragment order.  Must be re-run whenever the weights change (once per optimizer step). */
 int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W, const long* ldw, const int* K, const int* is_rec,
                  float* Wp, void* stream);
+/* The same for every cell of a model in one launch (the images of a LAS / DeepSpeech2 are refreshed together, once per step). */
+typedef struct asr_rnn_pack_desc {
+  int rnn_type, H, nseg;
+  const float* W[ASR_RNN_MAXSEG]; long ldw[ASR_RNN_MAXSEG]; int K[ASR_RNN_MAXSEG]; int is_rec[ASR_RNN_MAXSEG];
+  float* Wp;
+} asr_rnn_pack_desc;
+int asr_rnn_pack_many(int ncells, const asr_rnn_pack_desc* cells, void* stream);
 
 /* One cell step for one direction; row b of every matrix is at ptr + b * ld. */
 typedef struct asr_rnn_step_fwd {
@@ -355,6 +370,9 @@ typedef struct asr_rnn_seq_grad {
   float* direct[2];                         /* scratch [B,H] per direction (zeroed by the call)      */
   float* dh0[2]; long dh0_ld[2];            /* out: gradient wrt initial h or NULL                   */
   float* ds[2];                             /* asr_rnn_sweep_bwd only: out, the gate-sum gradients [B,T,NS*H], a buffer of its own */
+  float* db[2]; float* db_rec[2];           /* asr_rnn_sweep_bwd only, optional: bias gradients accumulated (+=) by the sweep itself - db [G*H] the
+                                               column sums of the input-side slots of ds (Keras bias, GRU: bias[0]), db_rec [3H] GRU's
+                                               recurrent bias (bias[1]) - instead of a separate pass over ds                                */
 } asr_rnn_seq_grad;
 /* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs (written in place over the
  * activations, one time step per launch).  asr_rnn_sweep_bwd writes them to g->ds[d] instead: its resident workgroups read the
@@ -453,6 +471,8 @@ typedef struct asr_decoder_sweep_grad {
   const float* U1; const float* W1; const float* U0; const float* W0;
   const uint32_t* seed; float drop_rate; uint32_t drop_stream0, drop_stream_step;
   float* ds0; float* ds1; float* de; float* dctx; float* dh_init; float* dc_init;
+  float* de_sum;                                  /* optional [B,T2]: sum over the steps of de - the gradient wrt the loop-invariant score term
+                                                     s0 = K bq of the hoisted attention (las.py:46-54), otherwise a [B,U,T2] x ones product */
 } asr_decoder_sweep_grad;
 int asr_decoder_sweep_bwd_supported(int rnn_type, int num_layers, int B, int U, int T2, int Hd, int D);
 long asr_decoder_sweep_bwd_ws_floats(int Hd, int D);

@@ -36,6 +36,11 @@ class RnnGeom(C.Structure):
     _fields_ = [("Q", C.c_int), ("KSt", C.c_int), ("ks0", C.c_int * RNN_MAXSEG), ("wp_floats", c_long)]
 
 
+class RnnPackDesc(C.Structure):
+    _fields_ = [("rnn_type", C.c_int), ("H", C.c_int), ("nseg", C.c_int), ("W", c_f32p * RNN_MAXSEG), ("ldw", c_long * RNN_MAXSEG),
+                ("K", C.c_int * RNN_MAXSEG), ("is_rec", C.c_int * RNN_MAXSEG), ("Wp", c_f32p)]
+
+
 class RnnStepFwd(C.Structure):
     _fields_ = [("nseg", C.c_int), ("KSt", C.c_int), ("Wp", c_f32p), ("Wp16", c_f32p),
                 ("seg_x", c_f32p * RNN_MAXSEG), ("seg_ld", c_long * RNN_MAXSEG),
@@ -92,13 +97,14 @@ class DecoderSweepGrad(C.Structure):
                 ("cin", c_f32p), ("c0", c_f32p), ("tokmask", c_f32p), ("dy1", c_f32p), ("dy1_ld", c_long),
                 ("U1", c_f32p), ("W1", c_f32p), ("U0", c_f32p), ("W0", c_f32p),
                 ("seed", c_f32p), ("drop_rate", C.c_float), ("drop_stream0", C.c_uint32), ("drop_stream_step", C.c_uint32),
-                ("ds0", c_f32p), ("ds1", c_f32p), ("de", c_f32p), ("dctx", c_f32p), ("dh_init", c_f32p), ("dc_init", c_f32p)]
+                ("ds0", c_f32p), ("ds1", c_f32p), ("de", c_f32p), ("dctx", c_f32p), ("dh_init", c_f32p), ("dc_init", c_f32p),
+                ("de_sum", c_f32p)]
 
 
 class RnnSeqGrad(C.Structure):
     _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
                 ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("direct", c_f32p * 2), ("dh0", c_f32p * 2),
-                ("dh0_ld", c_long * 2), ("ds", c_f32p * 2)]
+                ("dh0_ld", c_long * 2), ("ds", c_f32p * 2), ("db", c_f32p * 2), ("db_rec", c_f32p * 2)]
 
 
 class ConvDesc(C.Structure):
@@ -122,7 +128,7 @@ class AudioInfo(C.Structure):
 
 AUDIO_FORMATS = {"wav": 0, "flac": 1, "pcm": 2}
 
-STRUCTS = {"asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom, "asr_audio_info_t": AudioInfo,
+STRUCTS = {"asr_rnn_pack_desc": RnnPackDesc, "asr_logmel_cfg": LogmelCfg, "asr_gemm_desc": GemmDesc, "asr_rnn_geom": RnnGeom, "asr_audio_info_t": AudioInfo,
            "asr_rnn_step_fwd": RnnStepFwd, "asr_rnn_back_src": RnnBackSrc, "asr_rnn_step_bwd": RnnStepBwd, "asr_rnn_seq": RnnSeq,
            "asr_rnn_seq_grad": RnnSeqGrad, "asr_decoder_sweep": DecoderSweep, "asr_decoder_sweep_grad": DecoderSweepGrad, "asr_conv_desc": ConvDesc, "asr_rowdrop": RowDrop,
            "asr_lr_schedule": LrSchedule}
@@ -143,6 +149,8 @@ SIGNATURES = {
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), _P, _P]),
+    "asr_rnn_pack_many": (C.c_int, [C.c_int, C.POINTER(RnnPackDesc), _P]),
+    "asr_dropout_tables": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_uint32), C.POINTER(C.c_float), _P, _P]),
     "asr_rnn_cell_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepFwd), _P, _P]),
     "asr_rnn_cell_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(RnnStepBwd), _P, _P]),
     "asr_f32_to_bf16": (C.c_int, [_P, _P, c_long, _P]),
@@ -176,6 +184,9 @@ SIGNATURES = {
     "asr_fill_f32": (C.c_int, [_P, c_long, C.c_float, _P]),
     "asr_frame_mask": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "asr_colsum": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P]),
+    "asr_colsum_weighted": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P, _P]),
+    "asr_rowdot": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P, _P]),
+    "asr_rank1_add": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P, _P]),
     "asr_bn_fwd": (C.c_int, [_P, C.c_int, C.c_int, c_long, _P, _P, C.c_float, C.c_float, C.c_int, C.c_int, _P, c_long,
                              _P, _P, _P, _P, _P, _P]),
     "asr_bn_bwd": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, c_long, c_long, c_long, _P, _P, _P, C.c_int, _P, c_long, _P,

@@ -23,6 +23,7 @@ extern "C" long asr_struct_size(const char* name) {
   SZ(asr_logmel_cfg);
   SZ(asr_gemm_desc);
   SZ(asr_rnn_geom);
+  SZ(asr_rnn_pack_desc);
   SZ(asr_rnn_step_fwd);
   SZ(asr_rnn_back_src);
   SZ(asr_rnn_step_bwd);

@@ -40,6 +40,7 @@ struct DbArgs {
   const float* U1; const float* W1; const float* U0; const float* W0c; long ldw;
   const uint32_t* seed; float rate; uint32_t stream0, stream_step;
   float* de; float* dctx; float* dhs; float* dc;
+  float* de_sum;                            // optional [B,T2]: sum over the steps of de (the gradient wrt the constant score term s0 = K bq)
   float* xbuf; long xbytes;
   long o_p1, o_c1, o_p0, o_c0, o_pc, o_q, slot_floats;
   unsigned* err; float* err_flag;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
       }
     }
     const long my_p = ((long)(tile * G + gj) * G + gi) * blkf + (long)nt_ * 256 + lane * 4;   // block (row gj, sender gi), this wave's tile
+    float de_acc = 0.f;                                  // (wave 3 of an attention workgroup) this lane's frame: de summed over the steps
     for (int p = 0; p < U; ++p) {
       const int i = U - 1 - p;
       const long slot_cur = (long)(p & 3) * a.slot_floats, slot_old = (long)((p + 2) & 3) * a.slot_floats;
@@ -613,8 +615,10 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
         const long row = (long)i * a.Bs + ab;
         if (lane < FS) a.dctx[row * D + FS * ac + lane] = dcv;
         if (lane < nt) a.de[row * T2 + t_lo + lane] = dev;
+        if (lane < nt) de_acc += dev;
       }
     }
+    if (attn && sw == 3 && a.de_sum && lane < nt && !*abort_flag) a.de_sum[(long)ab * T2 + t_lo + lane] = de_acc;
   }
   __syncthreads();
   if (*abort_flag && tid == 0) {
@@ -722,6 +726,7 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
     a.saved0 = s->saved0 + b0 * 4 * Hd; a.saved1 = s->saved1 + b0 * 4 * Hd; a.ds0 = s->ds0 + b0 * 4 * Hd; a.ds1 = s->ds1 + b0 * 4 * Hd;
     a.cin = s->cin + b0 * Hd; a.c0 = s->c0 + b0 * Hd; a.tokmask = s->tokmask + b0; a.dy1 = s->dy1 + b0 * s->dy1_ld;
     a.de = s->de + b0 * T2; a.dctx = s->dctx + b0 * D; a.dhs = s->dh_init + b0 * Hd; a.dc = s->dc_init + b0 * Hd;
+    a.de_sum = s->de_sum ? s->de_sum + b0 * T2 : nullptr;
     const size_t n = (size_t)xfloats;
     hipLaunchKernelGGL(sw_fill_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st,
                        reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);

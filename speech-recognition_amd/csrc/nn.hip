@@ -75,6 +75,77 @@ extern "C" int asr_colsum(const float* A, int M, int N, long lda, float* out, vo
   return ASR_OK;
 }
 
+// ------------------------------------------------------------------------------------------ one-column products of the attention (las.py:46-59)
+// The hoisted attention has three products with a dimension of ONE - s0 = K bq, d bq = K^T ds0 and the rank-1 term ds0 (x) bq of dK.
+// Through the MFMA GEMM each of them is a launch of 24-42 us that moves 8 MB; as memory-bound kernels they take 5-8.
+// out[c] (+)= sum_r w[r] A[r][c]: colsum_kernel with a weight per row
+__global__ __launch_bounds__(256) void colsum_w_kernel(const float* A, int M, int N, long lda, const float* w, float* out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int r = r0 + wv;
+    for (; r + 12 < r1; r += 16) {
+      const float* q = A + (long)r * lda + c;
+      const float v0 = q[0], v1 = q[4 * lda], v2 = q[8 * lda], v3 = q[12 * lda];
+      p0 = fmaf(w[r], v0, p0); p1 = fmaf(w[r + 4], v1, p1); p2 = fmaf(w[r + 8], v2, p2); p3 = fmaf(w[r + 12], v3, p3);
+    }
+    for (; r < r1; r += 4) p0 = fmaf(w[r], A[(long)r * lda + c], p0);
+    s = (p0 + p1) + (p2 + p3);
+  }
+  red[wv][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (wv == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+extern "C" int asr_colsum_weighted(const float* A, int M, int N, long lda, const float* w, float* out, void* stream) {
+  ASR_CHECK(A && w && out && M > 0 && N > 0 && lda >= N, ASR_ERR_ARG, "asr_colsum_weighted: bad argument");
+  const int rpb = 128;
+  hipLaunchKernelGGL(colsum_w_kernel, dim3((unsigned)asr_cdiv(N, 64), (unsigned)asr_cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, A, M, N, lda, w,
+                     out, rpb);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+// y[r] = A[r][:] . x  (one wave per row, 4 rows per workgroup)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* A, int M, int K, long lda, const float* x, float* y) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= M) return;
+  const float* a = A + (long)r * lda;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(a[k], x[k], s);
+  s = wave_sum(s);
+  if (lane == 0) y[r] = s;
+}
+extern "C" int asr_rowdot(const float* A, int M, int K, long lda, const float* x, float* y, void* stream) {
+  ASR_CHECK(A && x && y && M > 0 && K > 0 && lda >= K, ASR_ERR_ARG, "asr_rowdot: bad argument");
+  hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)asr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, A, M, K, lda, x, y);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+// C[r][c] += u[r] v[c]
+__global__ __launch_bounds__(256) void rank1_add_kernel(float* C, int M, int N, long ldc, const float* u, const float* v) {
+  const long n4 = N >> 2, total = (long)M * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / n4, c = (i % n4) * 4;
+    float4* dst = reinterpret_cast<float4*>(C + r * ldc + c);
+    const float4 vv = *reinterpret_cast<const float4*>(v + c);
+    const float ur = u[r];
+    float4 t = *dst;
+    t.x = fmaf(ur, vv.x, t.x); t.y = fmaf(ur, vv.y, t.y); t.z = fmaf(ur, vv.z, t.z); t.w = fmaf(ur, vv.w, t.w);
+    *dst = t;
+  }
+}
+extern "C" int asr_rank1_add(float* C, int M, int N, long ldc, const float* u, const float* v, void* stream) {
+  ASR_CHECK(C && u && v && M > 0 && N > 0 && N % 4 == 0 && ldc >= N && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)v & 15) == 0, ASR_ERR_ARG,
+            "asr_rank1_add: bad argument (N and ldc multiples of 4, 16-byte aligned C and v)");
+  const long total = (long)M * (N >> 2);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(rank1_add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, M, N, ldc, u, v);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ batch norm
 // BatchNormalization(axis=-1, eps=1e-3, momentum=0.99) in training mode (las.py:170,193;
 // deepspeech2.py:112,118): biased batch statistics over all M rows (padded frames included).
@@ -284,6 +355,36 @@ extern "C" int asr_dropout_table(float* out, long n, const uint32_t* seed, uint3
   hipLaunchKernelGGL(dropout_table_kernel, dim3((unsigned)min((long)1024, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed,
                      stream_id, rate);
   ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+// several tables in one launch (blockIdx.y = table): the input-dropout tables of all BiRNN layers of a step depend on the seed only
+#define ASR_TABLES_MANY 16
+struct DropTables { float* out[ASR_TABLES_MANY]; long n[ASR_TABLES_MANY]; uint32_t stream_id[ASR_TABLES_MANY]; float rate[ASR_TABLES_MANY]; };
+__global__ void dropout_tables_kernel(DropTables t, const uint32_t* seed) {
+  const int k = blockIdx.y;
+  const AsrRngKey key = asr_rng_key(seed[0], t.stream_id[k]);
+  const uint32_t thr = asr_drop_threshold(t.rate[k]);
+  const float sc = 1.f / (1.f - t.rate[k]);
+  float* out = t.out[k];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n[k]; i += (long)gridDim.x * blockDim.x)
+    out[i] = asr_drop_mult(key, (uint32_t)i, thr, sc);
+}
+extern "C" int asr_dropout_tables(int ntables, float* const* outs, const long* ns, const uint32_t* stream_ids, const float* rates,
+                                  const uint32_t* seed, void* stream) {
+  ASR_CHECK(outs && ns && stream_ids && rates && seed && ntables > 0, ASR_ERR_ARG, "asr_dropout_tables: null argument");
+  for (int t0 = 0; t0 < ntables; t0 += ASR_TABLES_MANY) {
+    DropTables t{};
+    const int n = ntables - t0 < ASR_TABLES_MANY ? ntables - t0 : ASR_TABLES_MANY;
+    long nmax = 0;
+    for (int k = 0; k < n; ++k) {
+      ASR_CHECK(outs[t0 + k] && ns[t0 + k] > 0 && rates[t0 + k] > 0.f && rates[t0 + k] < 1.f, ASR_ERR_ARG, "asr_dropout_tables: bad table %d", t0 + k);
+      t.out[k] = outs[t0 + k]; t.n[k] = ns[t0 + k]; t.stream_id[k] = stream_ids[t0 + k]; t.rate[k] = rates[t0 + k];
+      nmax = ns[t0 + k] > nmax ? ns[t0 + k] : nmax;
+    }
+    hipLaunchKernelGGL(dropout_tables_kernel, dim3((unsigned)min((long)64, (nmax + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t, seed);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }
 

@@ -75,6 +75,21 @@ __global__ void rnn_pack_kernel(PackArgs a) {
   }
 }
 
+// every cell of a model in one launch (blockIdx.y = cell): the images are refreshed once per optimizer step, and eight 5-us
+// launches of a few hundred KB each are mostly launch latency
+#define ASR_PACK_MANY 12
+struct PackManyArgs { PackArgs c[ASR_PACK_MANY]; };
+__global__ void rnn_pack_many_kernel(PackManyArgs m) {
+  const PackArgs& a = m.c[blockIdx.y];
+  const long nf = (long)a.Q * a.KSt * 256;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long r = i >> 8;
+    const int blk = (int)(r % a.KSt), q = (int)(r / a.KSt);
+    a.Wp[i] = pack_value(a, q, 16 * blk + 4 * (lane >> 4) + e, lane & 15);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward step
 struct FwdSeg {
   const float* x; long ld; int K; int ks0; int vec;
@@ -441,6 +456,32 @@ extern "C" int asr_rnn_pack(int rnn_type, int H, int nseg, const float* const* W
   const long n = g.wp_floats;
   hipLaunchKernelGGL(rnn_pack_kernel, dim3((unsigned)min((long)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_rnn_pack_many(int ncells, const asr_rnn_pack_desc* cells, void* stream) {
+  ASR_CHECK(cells && ncells > 0, ASR_ERR_ARG, "asr_rnn_pack_many: null argument");
+  for (int c0 = 0; c0 < ncells; c0 += ASR_PACK_MANY) {
+    PackManyArgs m{};
+    const int n = ncells - c0 < ASR_PACK_MANY ? ncells - c0 : ASR_PACK_MANY;
+    long nmax = 0;
+    for (int c = 0; c < n; ++c) {
+      const asr_rnn_pack_desc& d = cells[c0 + c];
+      ASR_CHECK(d.Wp && d.nseg >= 1 && d.nseg <= ASR_RNN_MAXSEG, ASR_ERR_ARG, "asr_rnn_pack_many: bad cell %d", c0 + c);
+      asr_rnn_geom g;
+      int rc = asr_rnn_geometry(d.rnn_type, d.H, d.nseg, d.K, &g);
+      if (rc) return rc;
+      PackArgs& a = m.c[c];
+      for (int i = 0; i < d.nseg; ++i) {
+        ASR_CHECK(d.W[i], ASR_ERR_ARG, "asr_rnn_pack_many: null weight (cell %d, segment %d)", c0 + c, i);
+        a.W[i] = d.W[i]; a.ldw[i] = d.ldw[i]; a.K[i] = d.K[i]; a.ks0[i] = g.ks0[i]; a.is_rec[i] = d.is_rec[i];
+      }
+      a.nseg = d.nseg; a.KSt = g.KSt; a.NT = g.KSt; a.H = d.H; a.Q = g.Q; a.cell = cell_from_name(d.rnn_type); a.Wp = d.Wp;
+      nmax = g.wp_floats > nmax ? g.wp_floats : nmax;
+    }
+    hipLaunchKernelGGL(rnn_pack_many_kernel, dim3((unsigned)min((long)256, (nmax + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, m);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }
 

@@ -56,6 +56,8 @@ struct SbDir {
   const float* U; long ldu;
   const float* coef;            // [B,T,H,CW]: the element-wise backward as coefficients, written by the forward sweep (asr_rnn_seq.coef)
   float* ds;                    // [B,T,NS*H]: gate-sum gradients out (a buffer nobody in this launch reads)
+  float* db; float* db_rec;     // optional bias gradients (+=): db[NG*H] = sum over rows and steps of the input-side slots; GRU also db_rec[3H]
+                                // (recurrent bias: slots z, r and the recurrent part of h~).  Saves a pass over ds per direction (asr_colsum)
   const float* dh_last; long dh_last_ld;
   float* dc;                    // [B,H] in: d/d final c, out: d/d initial c (LSTM)
   float* dh0; long dh0_ld;
@@ -376,6 +378,9 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
     const bool writer = gj_ == 0 && !(a.dbg & 16);                    // column 0 of the square writes the layer's ds
+    f32x4 bsum[NS];                                                   // this lane's pieces summed over the steps: the bias gradient
+#pragma unroll
+    for (int k = 0; k < NS; ++k) bsum[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < T; ++p) {
       bool ok = true;
       for (int i = 0;; ++i) {
@@ -407,12 +412,42 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         constexpr int PPR = NS * 4 * NT;                               // pieces per batch row
         const int step = T - 1 - p, t = d.reverse ? T - 1 - step : step;
 #pragma unroll
-        for (int q = nt_ * 64 + lane; q < 16 * PPR; q += 64 * NT) {
+        for (int k = 0; k < NS; ++k) {
+          const int q = nt_ * 64 + lane + k * 64 * NT;                 // (16 * PPR = NS * 64 NT pieces: NS per lane, the same ones every step)
           const int row = q / PPR, rem = q % PPR, gate = rem / (4 * NT), u4 = rem % (4 * NT);
           const int sl = CELL == CELL_GRU ? (gate == 2 ? 3 : (gate == 3 ? 2 : gate)) : gate;   // image slot of this output slot
           const float* src = &tr[p % 3][u4 / NT][row][16 * (u4 % NT) + sl];
           const f32x4 v = {src[0], src[4], src[8], src[12]};
           if (b0 + row < B) *reinterpret_cast<f32x4*>(d.ds + ((long)(b0 + row) * T + t) * NS * H + (long)gate * H + gi_ * KU + 4 * u4) = v;
+          bsum[k] += v;                                                // (rows beyond B carry zeros)
+        }
+      }
+    }
+    if (writer && d.db && !*(volatile int*)&abort_flag) {
+      // bias gradient.  A lane's NS pieces are the same (gate, unit quad) of different rows (64 NT k is a multiple of PPR), and so are
+      // the lanes PPR apart: sum them in registers and across the wave first, then ONE atomic per bias element and wave (summing
+      // every lane's pieces with atomics - 16 colliding adds per element - cost the GRU layers more than the pass over ds it replaces)
+      constexpr int PPR = NS * 4 * NT;
+      f32x4 tot = bsum[0];
+#pragma unroll
+      for (int k = 1; k < NS; ++k) tot += bsum[k];
+#pragma unroll
+      for (int s2 = PPR; s2 < 64; s2 <<= 1) {
+        tot.x += __shfl_xor(tot.x, s2, 64); tot.y += __shfl_xor(tot.y, s2, 64);
+        tot.z += __shfl_xor(tot.z, s2, 64); tot.w += __shfl_xor(tot.w, s2, 64);
+      }
+      if (lane < PPR) {
+        const int rem = (nt_ * 64 + lane) % PPR, gate = rem / (4 * NT), u4 = rem % (4 * NT);
+        const int j0 = gi_ * KU + 4 * u4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = tot[e];
+          if (CELL == CELL_GRU) {                                      // slots z, r, x-part of h~, recurrent part of h~
+            if (gate < 3) atomicAdd(d.db + (long)gate * H + j0 + e, v);
+            if (gate != 2 && d.db_rec) atomicAdd(d.db_rec + (long)(gate == 3 ? 2 : gate) * H + j0 + e, v);
+          } else {
+            atomicAdd(d.db + (long)gate * H + j0 + e, v);
+          }
         }
       }
     }
@@ -528,7 +563,7 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
     ASR_CHECK(gs->ds[d] && (const float*)gs->ds[d] != s->coef[d], ASR_ERR_ARG, "asr_rnn_sweep_bwd: g->ds[%d] missing", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
     SbDir& p = a.d[d];
-    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.coef = s->coef[d]; p.ds = gs->ds[d];
+    p.U = s->U[d]; p.ldu = s->ldu[d] ? s->ldu[d] : (long)NG * H; p.coef = s->coef[d]; p.ds = gs->ds[d]; p.db = gs->db[d]; p.db_rec = gs->db_rec[d];
     p.dh_last = gs->dh_last[d]; p.dh_last_ld = gs->dh_last_ld[d];
     p.dc = gs->dc[d]; p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];
     p.reverse = s->reverse[d]; p.y_col = s->y_col[d];

@@ -234,6 +234,17 @@ class BiRNN:
         for d in range(2):
             self.cells[d].pack([(self.store.p[self.names[d] + "recurrent_kernel"], True)])
 
+    def pack_list(self):
+        """(cell, weights) pairs of this layer for ops.pack_cells (one launch for a whole model)."""
+        return [(self.cells[d], [(self.store.p[self.names[d] + "recurrent_kernel"], True)]) for d in range(2)]
+
+    def dropout_table_list(self, buf, training):
+        """(table, stream, rate) of this layer's input-dropout tables for ops.dropout_tables (one launch for a whole model); forward()
+        called with tables_ready=True then does not draw them again."""
+        if not (training and self.dropout > 0):
+            return []
+        return [(dd["mtab"], self.stream_in + d, self.dropout) for d, dd in enumerate(buf["dirs"])]
+
     def alloc(self, B, T, device="cuda"):
         H, rt = self.H, self.rt
         f = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
@@ -268,7 +279,7 @@ class BiRNN:
                 out.append(dd["cseq"][:, tl])
         return out
 
-    def forward(self, buf, x3d, mask, init_states, training, seed):
+    def forward(self, buf, x3d, mask, init_states, training, seed, tables_ready=False):
         B, T, H, rt = buf["B"], buf["T"], self.H, self.rt
         nst = 2 if rt == "lstm" else 1
         x2d = x3d.reshape(B * T, self.Din)
@@ -281,7 +292,7 @@ class BiRNN:
                 ops.dropout_table(dd["rtab"], seed, self.stream_rec + d, self.recurrent_dropout)
                 dd["rec_mult"] = dd["rtab"]
             W, b = p[self.names[d] + "kernel"], p[self.names[d] + "bias"]
-            if drop:
+            if drop and not tables_ready:
                 ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
             ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=(b[0] if rt == "gru" else b), a_scale=dd["mtab"] if drop else None, a_rpg=T)
             dd["bias_rec"] = b[1] if rt == "gru" else None
@@ -335,9 +346,12 @@ class BiRNN:
         for d, dd in enumerate(buf["dirs"]):
             if buf["mask"] is not None:
                 ops.fill(dd["dy_carry"], 0.0)
+            gb = self.store.g[self.names[d] + "bias"]
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
                             dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"],
-                            ds=dd["ds"] if pws is not None else None))
+                            ds=dd["ds"] if pws is not None else None,
+                            # the BPTT sweep sums the bias gradients itself (no second pass over ds)
+                            db=(gb[0] if rt == "gru" else gb) if pws is not None else None, db_rec=gb[1] if (rt == "gru" and pws is not None) else None))
         dskey = "ds" if pws is not None else "saved"     # where this backward pass leaves the gate-sum gradients
         sweep = lambda: ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
         if overlap is not None:
@@ -353,7 +367,7 @@ class BiRNN:
                 ds3 = dd[dskey]
                 ds2 = ds3.view(B * T, -1)
                 mt = dd["mtab"] if buf["drop"] else None
-                cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, g[nm + "bias"], a_scale=mt, a_rpg=T)
+                cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, None if pws is not None else g[nm + "bias"], a_scale=mt, a_rpg=T)
                 # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
                 hs = dd["hseq"]
                 # recurrent dropout: the cell multiplied (h_prev * rtab[b]) into U - scale the stored states the same way

@@ -135,8 +135,7 @@ class DeepSpeech2(ModelProto):
     def pack_weights(self):
         if ops.mixed_precision():
             self.store.refresh_bf16()
-        for l in self.layers:
-            l.pack()
+        ops.pack_cells([cw for l in self.layers for cw in l.pack_list()])      # all 14 cells in one launch (two at more than 12)
         self._packed_version = self._version
 
     @property
@@ -198,8 +197,9 @@ class DeepSpeech2(ModelProto):
             x = y
         x3 = x.view(B, T2, self.D0)
         states = None
+        ops.dropout_tables([t for l, lw in zip(self.layers, ws.layers) for t in l.dropout_table_list(lw["rnn"], training)], self.seed)
         for i, (l, lw) in enumerate(zip(self.layers, ws.layers)):
-            y = l.forward(lw["rnn"], x3, ws.mask, states, training, self.seed)
+            y = l.forward(lw["rnn"], x3, ws.mask, states, training, self.seed, tables_ready=True)
             states = l.final_states(lw["rnn"])
             bn = f"recurrent/batch_norm/{i}/"
             ops.bn_fwd(y.view(B * T2, 2 * H), p[bn + "gamma"], p[bn + "beta"], lw["a"], lw["mean"], lw["rstd"],

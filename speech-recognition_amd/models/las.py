@@ -218,12 +218,12 @@ class LAS(ModelProto):
         p = self.store.p
         if ops.mixed_precision():
             self.store.refresh_bf16()
-        for l in self.enc_layers:
-            l.pack()
+        cells = [cw for l in self.enc_layers for cw in l.pack_list()]
         for j, cell in enumerate(self.dec_cells):
             pre = f"attend_and_speller/decoder_layers/{j}/cell/"
             W = p[pre + "kernel"]
-            cell.pack([(W[self.Hd:] if j == 0 else W, False), (p[pre + "recurrent_kernel"], True)])
+            cells.append((cell, [(W[self.Hd:] if j == 0 else W, False), (p[pre + "recurrent_kernel"], True)]))
+        ops.pack_cells(cells)                              # every cell of the model in one launch
         self._packed_version = self._version
 
     # ------------------------------------------------------------------------------------------ workspaces
@@ -312,8 +312,9 @@ class LAS(ModelProto):
         ops.conv2d_fwd(ws.c1, p["listener/conv2/kernel"], p["listener/conv2/bias"], 2, ws.c2, self.seed, R.STREAM_CONV2_DROP, rate)
         x3 = ws.c2.view(B, T2, self.D0)
         states = None
+        ops.dropout_tables([t for l, lw in zip(self.enc_layers, ws.layers) for t in l.dropout_table_list(lw["rnn"], training)], self.seed)
         for i, (l, lw) in enumerate(zip(self.enc_layers, ws.layers)):
-            y = l.forward(lw["rnn"], x3, ws.mask, states, training, self.seed)
+            y = l.forward(lw["rnn"], x3, ws.mask, states, training, self.seed, tables_ready=True)
             states = l.final_states(lw["rnn"])
             ops.gemm(y.view(B * T2, 2 * He), p[f"listener/projection/{i}/kernel"], lw["z"], bias=p[f"listener/projection/{i}/bias"])
             bn = f"listener/batch_norm/{i}/"
@@ -334,7 +335,7 @@ class LAS(ModelProto):
         a = "attend_and_speller/attention/"
         ops.gemm(ws.enc, p[a + "key_weight/kernel"], ws.K, bias=p[a + "key_weight/bias"])
         ops.gemm(ws.K, p[a + "query_weight/kernel"], ws.Kq, trans_b=True)
-        ops.gemm(ws.K, p[a + "query_weight/bias"].view(self.Hd, 1), ws.s0)
+        ops.rowdot(ws.K, p[a + "query_weight/bias"], ws.s0.view(-1))                         # s0 = K bq
         # mixed precision: the decoder steps stream Kq and enc once each per step - give them bf16 images (wide models only:
         # on las_small the streams sit in L2 / Infinity Cache and the steps are latency-bound either way)
         ws.attn_images = None
@@ -497,6 +498,7 @@ class LAS(ModelProto):
         d.drop_rate, d.drop_stream0, d.drop_stream_step = rate, R.STREAM_DEC, R.DEC_STREAMS_PER_STEP
         d.ds0, d.ds1 = ws.dec[0]["ds"].data_ptr(), ws.dec[1]["ds"].data_ptr()
         d.de, d.dctx, d.dh_init, d.dc_init = ws.ds.data_ptr(), ws.dctx.data_ptr(), ws.dhs.data_ptr(), ws.dc_dec.data_ptr()
+        d.de_sum = ws.ds0.data_ptr()                # sum_i de[i] = the gradient wrt s0, for free (otherwise a product with a column of ones)
         ops.decoder_sweep_bwd(d, ws.dsweep_bwd_ws, getattr(self.store, "err_flag", None))
 
     # ------------------------------------------------------------------------------------------ forward
@@ -706,15 +708,16 @@ class LAS(ModelProto):
         ds_b = ws.ds.permute(1, 0, 2)                      # [B, U, T2] views of the step-major buffers
         hin_b = ws.hin[:U].permute(1, 0, 2)
         ops.gemm(ds_b, hin_b, ws.dKq.view(B, T2, Hd), trans_a=True)                       # dKq[b] = ds[b]^T hin[b]
-        ops.gemm(ds_b, ws.ones_u.expand(B, U, 1), ws.ds0.view(B, T2, 1), trans_a=True)     # ds0[b,t] = sum_i ds[b,i,t]
+        if not swept:                                      # (the backward sweep leaves ds0[b,t] = sum_i ds[b,i,t] behind)
+            ops.gemm(ds_b, ws.ones_u.expand(B, U, 1), ws.ds0.view(B, T2, 1), trans_a=True)
         ops.gemm(ws.p.permute(1, 0, 2), ws.dctx.permute(1, 0, 2), ws.denc.view(B, T2, 2 * He), trans_a=True)  # p^T dctx
         ops.gemm(ws.dKq, Wq, ws.dK)                                                       # dK = dKq Wq
-        ops.gemm(ws.ds0, bq.view(1, Hd), ws.dK, accumulate=1)                             #    + ds0 (x) bq
+        ops.rank1_add(ws.dK, ws.ds0.view(-1), bq)                                         #    + ds0 (x) bq
         dense_bwd(ws.enc, Wk, ws.dK, None, None, ws.denc, dx_accumulate=True)             # d enc += dK Wk^T
 
         def attention_weight_grads():
             ops.gemm(ws.dKq, ws.K, g[a + "query_weight/kernel"], trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
-            ops.gemm(ws.K, ws.ds0, g[a + "query_weight/bias"].view(Hd, 1), trans_a=True, accumulate=1, split_k=max(1, (B * T2) // 256))
+            ops.colsum_weighted(ws.K, ws.ds0.view(-1), g[a + "query_weight/bias"])       # d bq += K^T ds0
             dense_bwd(ws.enc, None, ws.dK, g[a + "key_weight/kernel"], g[a + "key_weight/bias"])
         ov.defer(attention_weight_grads)
         # ---- listener state projections (las.py:196-202): the gradients wrt the encoder's final states first

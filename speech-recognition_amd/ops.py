@@ -377,6 +377,32 @@ class PackedCell:
     def wp16_ptr(self):
         return self.Wp16.data_ptr() if (self.Wp16 is not None and mixed_precision()) else None
 
+    def pack_desc(self, weights):
+        """asr_rnn_pack_desc of this cell for pack_cells()."""
+        n = len(weights)
+        assert n == len(self.Ks)
+        d = _lib.RnnPackDesc()
+        d.rnn_type, d.H, d.nseg = rnn_type_id(self.rnn_type), self.H, n
+        for i, ((w, rec), k) in enumerate(zip(weights, self.Ks)):
+            _dev(w, name="weight")
+            assert w.shape[0] == k and w.stride(1) == 1
+            d.W[i], d.ldw[i], d.K[i], d.is_rec[i] = w.data_ptr(), w.stride(0), k, int(rec)
+        d.Wp = self.Wp.data_ptr()
+        return d
+
+
+def pack_cells(cells_and_weights):
+    """PackedCell.pack for many cells in ONE launch (asr_rnn_pack_many): [(cell, weights), ...]."""
+    if not cells_and_weights:
+        return
+    descs = (_lib.RnnPackDesc * len(cells_and_weights))(*[c.pack_desc(w) for c, w in cells_and_weights])
+    check(lib().asr_rnn_pack_many(len(cells_and_weights), descs, _stream()))
+    if mixed_precision():
+        for c, _ in cells_and_weights:
+            if c.Wp16 is None:
+                c.Wp16 = torch.empty(c.Wp.numel(), device=c.Wp.device, dtype=torch.bfloat16)
+            f32_to_bf16(c.Wp, c.Wp16)
+
 
 def _arr2(vals, ctype=C.c_void_p):
     vals = list(vals) + [None] * (2 - len(vals))
@@ -522,6 +548,8 @@ def rnn_seq_bwd(seq, dy, dirs_grad, persist_ws=None, err_flag=None):
     g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
     g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
     g.ds = _arr2([d.get("ds") for d in dirs_grad])
+    g.db = _arr2([d.get("db") for d in dirs_grad])
+    g.db_rec = _arr2([d.get("db_rec") for d in dirs_grad])
     if persist_ws is not None:
         check(lib().asr_rnn_sweep_bwd(C.byref(seq), C.byref(g), _p(persist_ws), _p(err_flag), _stream()))
     else:
@@ -682,6 +710,24 @@ def colsum(a, out):
     return out
 
 
+def colsum_weighted(a, w, out):
+    """out[c] += sum_r w[r] a[r, c] (a 2-D with unit inner stride, w [rows] contiguous)."""
+    check(lib().asr_colsum_weighted(_p(a), a.shape[0], a.shape[1], a.stride(0), _p(w), _p(out), _stream()))
+    return out
+
+
+def rowdot(a, x, y):
+    """y[r] = a[r, :] . x."""
+    check(lib().asr_rowdot(_p(a), a.shape[0], a.shape[1], a.stride(0), _p(x), _p(y), _stream()))
+    return y
+
+
+def rank1_add(c, u, v):
+    """c[r, :] += u[r] * v."""
+    check(lib().asr_rank1_add(_p(c), c.shape[0], c.shape[1], c.stride(0), _p(u), _p(v), _stream()))
+    return c
+
+
 def bn_fwd(x, gamma, beta, y, mean, rstd, moving_mean, moving_var, ws, *, relu, training, eps=1e-3, momentum=0.99):
     M, Cc = x.shape
     check(lib().asr_bn_fwd(_p(x), M, Cc, x.stride(0), _p(gamma), _p(beta), eps, momentum, int(relu), int(training), _p(y),
@@ -717,6 +763,20 @@ def dropout_table(out, seed, stream_id, rate):
     assert out.is_contiguous()
     check(lib().asr_dropout_table(_p(out), out.numel(), _p(seed), stream_id, float(rate), _stream()))
     return out
+
+
+def dropout_tables(tables, seed):
+    """Several dropout_table()s in one launch: tables = [(out, stream_id, rate), ...]."""
+    n = len(tables)
+    if n == 0:
+        return
+    outs = (C.c_void_p * n)(*[t[0].data_ptr() for t in tables])
+    ns = (C.c_long * n)(*[t[0].numel() for t in tables])
+    ids = (C.c_uint32 * n)(*[int(t[1]) for t in tables])
+    rates = (C.c_float * n)(*[float(t[2]) for t in tables])
+    for t in tables:
+        assert t[0].is_contiguous()
+    check(lib().asr_dropout_tables(n, outs, ns, ids, rates, _p(seed), _stream()))
 
 
 def embedding_fwd(E, tok, out, seed=None, drop1=None, drop2=None):
