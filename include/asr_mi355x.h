@@ -39,6 +39,9 @@ const char* asr_last_error(void);
 int asr_version(void);
 /* sizeof(struct <name>) as compiled into the library (-1 = unknown): lets a binding verify its mirror */
 long asr_struct_size(const char* name);
+/* Once per process, after loading: returns and clears the HIP runtime's sticky error left by earlier calls of this thread (a probe
+ * made before the device was initialised leaves hipErrorNoDevice behind).  The entry points never clear it themselves. */
+int asr_runtime_init(void);
 
 /* ------------------------------------------------------------------------------------------
  * Front end: log-mel + SpecAugment + delta/delta-delta + zero padding, one fused kernel.
@@ -348,8 +351,11 @@ typedef struct asr_rnn_seq {
   const float* bias_rec[2];                 /* GRU                                                   */
   const float* h0[2]; long h0_ld[2];        /* initial states (NULL = zeros)                         */
   const float* c0[2]; long c0_ld[2];
-  const float* rec_mult[2];                 /* [B,H] recurrent-dropout multipliers (constant over time, deepspeech2.py:95-107) or NULL;
-                                               per-step kernels only - the persistent launches reject it */
+  const float* rec_mult[2];                 /* recurrent-dropout multipliers (constant over time, deepspeech2.py:95-107) or NULL: ONE [B,H] TABLE
+                                               PER GATE, back to back ([4][B,H] LSTM i,f,c,o; [3][B,H] GRU z,r,h; [1][B,H] SimpleRNN) - tf.keras
+                                               switches its LSTM / GRU cells to implementation 1 whenever recurrent_dropout != 0, which masks
+                                               h_tm1 separately per gate and carries the GRU state unmasked.  Per-step kernels only - the
+                                               one-launch sweeps reject it */
   const uint8_t* mask;
   float* hseq[2]; float* cseq[2];
   float* y; long y_ld; int y_col[2];

@@ -84,12 +84,20 @@ def ds2_forward(p, cfg, audio, training=False, seed=0, mask_mode="intended", ret
         fwd = tuple(p[pre + "forward_rnn/cell/" + n] for n in ("kernel", "recurrent_kernel", "bias"))
         bwd = tuple(p[pre + "backward_rnn/cell/" + n] for n in ("kernel", "recurrent_kernel", "bias"))
         mf = mb = rf = rb = None
+        # [TF-sem] recurrent_dropout != 0 switches the Keras cells to implementation 1: one mask per gate on BOTH operands (streams of
+        # gate g: + 128 g); without it, implementation 2: a single input mask
+        ng = {"lstm": 4, "gru": 3, "rnn": 1}[rt]
+        per_gate = training and rrate > 0
         if training and rate > 0:
-            mf = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i, (B, x.shape[2]), rate, dt)
-            mb = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i + 1, (B, x.shape[2]), rate, dt)
-        if training and rrate > 0:
-            rf = L.dropout_mult(seed, STREAM_ENC_REC + 2 * i, (B, H), rrate, dt)
-            rb = L.dropout_mult(seed, STREAM_ENC_REC + 2 * i + 1, (B, H), rrate, dt)
+            if per_gate:
+                mf = [L.dropout_mult(seed, STREAM_ENC_IN + 2 * i + 128 * g, (B, x.shape[2]), rate, dt) for g in range(ng)]
+                mb = [L.dropout_mult(seed, STREAM_ENC_IN + 2 * i + 1 + 128 * g, (B, x.shape[2]), rate, dt) for g in range(ng)]
+            else:
+                mf = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i, (B, x.shape[2]), rate, dt)
+                mb = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i + 1, (B, x.shape[2]), rate, dt)
+        if per_gate:
+            rf = [L.dropout_mult(seed, STREAM_ENC_REC + 2 * i + 128 * g, (B, H), rrate, dt) for g in range(ng)]
+            rb = [L.dropout_mult(seed, STREAM_ENC_REC + 2 * i + 1 + 128 * g, (B, H), rrate, dt) for g in range(ng)]
         x, *states = L.birnn(rt, x, mask, fwd, bwd, states, mf, mb, rf, rb)
         bn = f"recurrent/batch_norm/{i}/"
         x, mm, mv = L.batch_norm(x, p[bn + "gamma"], p[bn + "beta"], p[bn + "moving_mean"],

@@ -66,6 +66,38 @@ def gru_cell(x, h, W, U, b):
     return h2, [h2]
 
 
+def lstm_cell_impl1(x, h, c, W, U, b, im, rm):
+    """Keras LSTMCell implementation 1 - what tf.keras uses whenever recurrent_dropout != 0 ([TF-sem] LSTMCell.__init__ forces it): one
+    dropout mask PER GATE on the input (im[g], or None) and on h_tm1 (rm[g], or None); each gate multiplies its own masked operands."""
+    H = h.shape[-1]
+    zs = []
+    for g in range(4):
+        xg = x if im is None else x * im[g]
+        hg = h if rm is None else h * rm[g]
+        zs.append(xg @ W[:, g * H:(g + 1) * H] + hg @ U[:, g * H:(g + 1) * H] + b[g * H:(g + 1) * H])
+    i, f, o = torch.sigmoid(zs[0]), torch.sigmoid(zs[1]), torch.sigmoid(zs[3])
+    c2 = f * c + i * torch.tanh(zs[2])
+    h2 = o * torch.tanh(c2)
+    return h2, [h2, c2]
+
+
+def gru_cell_impl1(x, h, W, U, b, im, rm):
+    """Keras GRUCell(reset_after=True) implementation 1 (forced by recurrent_dropout != 0): masks per gate z, r, h; the carry
+    z * h_tm1 uses the UNMASKED h_tm1."""
+    H = h.shape[-1]
+    mx, mh = [], []
+    for g in range(3):
+        xg = x if im is None else x * im[g]
+        hg = h if rm is None else h * rm[g]
+        mx.append(xg @ W[:, g * H:(g + 1) * H] + b[0][g * H:(g + 1) * H])
+        mh.append(hg @ U[:, g * H:(g + 1) * H] + b[1][g * H:(g + 1) * H])
+    z = torch.sigmoid(mx[0] + mh[0])
+    r = torch.sigmoid(mx[1] + mh[1])
+    hh = torch.tanh(mx[2] + r * mh[2])
+    h2 = z * h + (1.0 - z) * hh
+    return h2, [h2]
+
+
 def simple_rnn_cell(x, h, W, U, b):
     h2 = torch.tanh(x @ W + b + h @ U)
     return h2, [h2]
@@ -83,7 +115,9 @@ def rnn_layer(rnn_type, x, mask, W, U, b, initial_state=None, go_backwards=False
     is the previous emitted output (zeros before the first unmasked step).  go_backwards
     consumes input and mask reversed in time; outputs stay in *processing* order (the caller,
     BiRNN, re-reverses them: las.py:125).  Dropout multipliers in_mult/rec_mult are [B, D] /
-    [B, H], constant over time (Keras DropoutRNNCellMixin), applied to the input / to h.
+    [B, H], constant over time (Keras DropoutRNNCellMixin), applied to the input / to h.  A LIST of multipliers (one per gate:
+    4 for LSTM, 3 for GRU) selects Keras' implementation 1, which LSTM / GRU cells switch to whenever recurrent_dropout != 0
+    (per-gate masks on both operands, GRU carry on the unmasked state); a single tensor is implementation 2 (input dropout alone).
     Returns (outputs [B,T,H], [states...])."""
     if rnn_type not in ("rnn", "lstm", "gru"):
         raise ValueError(f"rnn_type: {rnn_type} is invalid!")
@@ -96,17 +130,26 @@ def rnn_layer(rnn_type, x, mask, W, U, b, initial_state=None, go_backwards=False
     order = range(T - 1, -1, -1) if go_backwards else range(T)
     prev_out = torch.zeros(B, H, dtype=x.dtype)
     outs = []
+    impl1 = isinstance(in_mult, (list, tuple)) or isinstance(rec_mult, (list, tuple))
+    if impl1 and rnn_type == "rnn":                     # SimpleRNN has one gate: one mask each
+        in_mult = in_mult[0] if isinstance(in_mult, (list, tuple)) else in_mult
+        rec_mult = rec_mult[0] if isinstance(rec_mult, (list, tuple)) else rec_mult
+        impl1 = False
     for t in order:
-        xt = x[:, t] if in_mult is None else x[:, t] * in_mult
-        h = states[0] if rec_mult is None else states[0] * rec_mult
-        if rnn_type == "lstm":
-            out, new = lstm_cell(xt, h, states[1], W, U, b)
-        elif rnn_type == "gru":
-            # [TF-sem] GRUCell implementation 2 rebinds h_tm1 to the masked value, so the
-            # z * h_tm1 carry term also sees the recurrent-dropout multiplier.
-            out, new = gru_cell(xt, h, W, U, b)
+        if impl1:
+            if rnn_type == "lstm":
+                out, new = lstm_cell_impl1(x[:, t], states[0], states[1], W, U, b, in_mult, rec_mult)
+            else:
+                out, new = gru_cell_impl1(x[:, t], states[0], W, U, b, in_mult, rec_mult)
         else:
-            out, new = simple_rnn_cell(xt, h, W, U, b)
+            xt = x[:, t] if in_mult is None else x[:, t] * in_mult
+            h = states[0] if rec_mult is None else states[0] * rec_mult
+            if rnn_type == "lstm":
+                out, new = lstm_cell(xt, h, states[1], W, U, b)
+            elif rnn_type == "gru":
+                out, new = gru_cell(xt, h, W, U, b)
+            else:
+                out, new = simple_rnn_cell(xt, h, W, U, b)
         m = mask[:, t][:, None]
         out = torch.where(m, out, prev_out)
         states = [torch.where(m, n, s) for n, s in zip(new, states)]

@@ -139,6 +139,7 @@ SIGNATURES = {
     "asr_last_error": (C.c_char_p, []),
     "asr_version": (C.c_int, []),
     "asr_struct_size": (c_long, [C.c_char_p]),
+    "asr_runtime_init": (C.c_int, []),
     "asr_logmel_table_sizes": (C.c_int, [C.POINTER(LogmelCfg), C.POINTER(c_long), C.POINTER(c_long), C.POINTER(c_long)]),
     "asr_logmel_build_tables": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, _P]),
     "asr_logmel_features": (C.c_int, [C.POINTER(LogmelCfg), _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
@@ -257,6 +258,7 @@ def load():
         n = lib.asr_struct_size(cname.encode())
         if n != C.sizeof(cls):
             raise ImportError(f"ABI mismatch: sizeof({cname}) is {n} in the library, {C.sizeof(cls)} in the binding")
+    lib.asr_runtime_init()               # drops a stale hipErrorNoDevice once; ASR_CHECK itself never touches the runtime's error state
     _lib = lib
     return lib
 

@@ -13,12 +13,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------- host-side status plumbing
 void asr_set_error(const char* fmt, ...);
-// (Every entry point validates its arguments with ASR_CHECK before it launches anything; the check also drops whatever error
-// an EARLIER runtime call of this thread left behind - hipGetLastError is sticky across libraries, and a stale
-// hipErrorNoDevice from a probe made before the device was initialised would otherwise be reported by the first launch check.)
+// (Every entry point validates its arguments with ASR_CHECK before it launches anything.  A pure argument check: it does NOT touch the
+// runtime's sticky error - an asynchronous failure left by another library (torch, RCCL) must stay visible to whoever launched it.
+// The one stale error this library knows of - hipErrorNoDevice from a probe made before the device was initialised - is dropped
+// once, by asr_runtime_init(), which the binding calls right after loading.)
 #define ASR_CHECK(cond, code, ...)          \
   do {                                      \
-    (void)hipGetLastError();                \
     if (!(cond)) {                          \
       asr_set_error(__VA_ARGS__);           \
       return (code);                        \

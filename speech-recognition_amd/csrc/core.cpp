@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/asr_mi355x.h"
 
 static thread_local char g_err[512] = "";
@@ -16,6 +18,11 @@ void asr_set_error(const char* fmt, ...) {
 
 extern "C" const char* asr_last_error(void) { return g_err; }
 extern "C" int asr_version(void) { return 100; }
+
+// Called once by the binding after the library (and the process's HIP runtime) is loaded: reports - and thereby clears - whatever
+// error an earlier runtime call of this thread left behind, so that the first ASR_LAUNCH_CHECK does not blame a launch for it.
+// Returns the hipError_t it found (0 = none); the entry points themselves never clear the runtime's error state.
+extern "C" int asr_runtime_init(void) { return (int)hipGetLastError(); }
 
 // sizeof of every ABI struct, so that a binding (ctypes, cgo, JNI...) can verify its mirror
 extern "C" long asr_struct_size(const char* name) {

@@ -94,7 +94,9 @@ __global__ void rnn_pack_many_kernel(PackManyArgs m) {
 struct FwdSeg {
   const float* x; long ld; int K; int ks0; int vec;
   int drop; uint32_t drop_stream; float drop_rate; long drop_ld; int drop_off;
-  const float* mult; long mult_ld;      // optional multiplier table [B, K] on this segment (Keras recurrent dropout: constant over time)
+  const float* mult; long mult_ld;      // optional multiplier tables [slots][B, K] on this segment (Keras recurrent dropout: constant over time)
+  long mult_gs;                         // floats between the tables of two gates: tf.keras switches its cells to implementation 1 whenever
+                                        // recurrent_dropout != 0 - ONE MASK PER GATE on h_tm1 - so the product is taken once per gate slot
 };
 struct FwdDir {
   FwdSeg seg[ASR_RNN_MAXSEG];
@@ -104,7 +106,6 @@ struct FwdDir {
   const float* pre; long pre_ld;
   const float* bias; const float* bias_rec;
   const float* h_prev; long h_prev_ld;
-  const float* hmult; long hmult_ld;    // recurrent-dropout multiplier of the owned (row, unit) pairs: the GRU z * h carry sees it too
   const float* c_prev; long c_prev_ld;
   const float* y_prev; long y_prev_ld;
   const uint8_t* mask; long mask_ld;
@@ -175,8 +176,7 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
     if (CELL == CELL_LSTM) cp = d.c_prev ? d.c_prev[(long)b * d.c_prev_ld + j] : 0.f;
     if (CELL == CELL_GRU && d.bias_rec) { br[0] = d.bias_rec[j]; br[1] = d.bias_rec[H + j]; br[2] = d.bias_rec[2L * H + j]; }
   }
-  float hpm = hp;
-  if (wave == 0 && live && d.hmult) hpm = hp * d.hmult[(long)b * d.hmult_ld + j];
+  const float hpm = hp;                 // (Keras implementation 1: the GRU carry z * h_tm1 takes the UNMASKED state)
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float4* wp = reinterpret_cast<const float4*>(d.Wp) + (long)q * d.KSt * 64 + lane;
@@ -221,23 +221,42 @@ __global__ __launch_bounds__(256) void rnn_step_fwd_kernel(FwdArgs a) {
           av[i].w *= asr_drop_mult(key, idx + 3, thr, dscale);
         }
       }
-      if (sg.mult && rowok) {
-        const float* mr = sg.mult + (long)brow * sg.mult_ld;
+      if (sg.mult) {
+        // per-gate masks: the packed columns of a tile are (slot, unit) = (li >> 2, li & 3); the A operand of an MFMA cannot depend
+        // on the output column, so the product runs once per slot with that slot's mask on h and every lane keeps the result of
+        // ITS column's slot.  Mask index of a packed slot: LSTM i, f, c~, o -> 0..3; GRU z, r, (x-part: no recurrent term), h~ -> 0, 1, -, 2
+        constexpr int NSLOT = CELL == CELL_RNN ? 1 : 4;
 #pragma unroll
-        for (int i = 0; i < RNN_CH; ++i) {
-          const int k = 16 * (j0 + 4 * i) + 4 * lq;
-          if (k < sg.K) av[i].x *= mr[k];
-          if (k + 1 < sg.K) av[i].y *= mr[k + 1];
-          if (k + 2 < sg.K) av[i].z *= mr[k + 2];
-          if (k + 3 < sg.K) av[i].w *= mr[k + 3];
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          if (CELL == CELL_GRU && sl == 2) continue;
+          const int mi = CELL == CELL_GRU && sl == 3 ? 2 : sl;
+          const float* mr = sg.mult + (long)mi * sg.mult_gs + (long)brow * sg.mult_ld;
+          f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < RNN_CH; ++i) {
+            const int k = 16 * (j0 + 4 * i) + 4 * lq;
+            float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowok) {
+              if (k < sg.K) m4.x = mr[k];
+              if (k + 1 < sg.K) m4.y = mr[k + 1];
+              if (k + 2 < sg.K) m4.z = mr[k + 2];
+              if (k + 3 < sg.K) m4.w = mr[k + 3];
+            }
+            accg = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x * m4.x, bv[i].x, accg, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y * m4.y, bv[i].y, accg, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z * m4.z, bv[i].z, accg, 0, 0, 0);
+            accg = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w * m4.w, bv[i].w, accg, 0, 0, 0);
+          }
+          if ((li >> 2) == sl || NSLOT == 1) acc += accg;
         }
-      }
+      } else {
 #pragma unroll
       for (int i = 0; i < RNN_CH; ++i) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[i].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+      }
       }
     }
   }
@@ -528,7 +547,8 @@ static int launch_fwd(int rnn_type, const FwdArgs& a, int ndir, hipStream_t st) 
   static const int wide = getenv("ASR_RNN_WIDE") ? atoi(getenv("ASR_RNN_WIDE")) : 1;
   static const int min_h = getenv("ASR_RNN_WIDE_MIN_H") ? atoi(getenv("ASR_RNN_WIDE_MIN_H")) : 512;   // tests lower it
   bool mult = false;                                             // recurrent dropout: narrow kernel only
-  for (int i = 0; i < ndir; ++i) mult = mult || a.d[i].hmult != nullptr;
+  for (int i = 0; i < ndir; ++i)
+    for (int sg = 0; sg < a.d[i].nseg; ++sg) mult = mult || a.d[i].seg[sg].mult != nullptr;
   if (wide && !mult && a.H >= min_h && a.B > 16) {
     launch_fwd_wide<2, 4, 16>(rnn_type, a, ndir, st);
     ASR_LAUNCH_CHECK();
@@ -597,8 +617,8 @@ extern "C" int asr_rnn_seq_fwd(const asr_rnn_seq* s, void* stream) {
       }
       fd.seg[0].x = fd.h_prev; fd.seg[0].ld = fd.h_prev_ld; fd.seg[0].K = H; fd.seg[0].ks0 = 0;
       fd.seg[0].vec = (((uintptr_t)fd.h_prev & 15) == 0) && (fd.h_prev_ld % 4 == 0);
-      fd.seg[0].mult = s->rec_mult[d]; fd.seg[0].mult_ld = H;       // deepspeech2.py:95-107 recurrent_dropout: h_tm1 * mask[B,H]
-      fd.hmult = s->rec_mult[d]; fd.hmult_ld = H;
+      fd.seg[0].mult = s->rec_mult[d]; fd.seg[0].mult_ld = H;       // deepspeech2.py:95-107 recurrent_dropout: h_tm1 * mask_g[B,H], one per gate
+      fd.seg[0].mult_gs = (long)B * H;
       fd.mask = s->mask ? s->mask + t : nullptr; fd.mask_ld = T;
       fd.h_out = hseq + (long)t * H; fd.h_out_ld = (long)T * H;
       fd.c_out = lstm ? cseq + (long)t * H : nullptr; fd.c_out_ld = (long)T * H;

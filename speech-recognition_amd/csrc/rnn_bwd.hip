@@ -28,7 +28,8 @@ struct BackSrc {
   const float* D; long ldd;
   const float* W; long ldw;
   const unsigned short* W16;     // bf16 image of W (same layout) or NULL
-  int nseg; int d_col0[2], w_col0[2], len[2];
+  int nseg; int d_col0[4], w_col0[4], len[4];
+  const float* oscale[4]; long oscale_ld;   // optional per-segment multiplier [B, n_units] on the segment's product (recurrent dropout: one mask per gate)
   int vec;
   float drop_rate; uint32_t drop_stream; long drop_ld; int drop_off;
 };
@@ -47,7 +48,6 @@ struct Bwd2Dir {
   const float* c_prev; long c_prev_ld;
   const float* c_out; long c_out_ld;
   float* dslots; long dslots_ld;
-  const float* rmult; long rmult_ld;   // recurrent-dropout multiplier [B, n_units] of the state this step hands back (or NULL)
 };
 struct Bwd2Args { Bwd2Dir d[2]; int B; const uint32_t* seed; };
 
@@ -61,6 +61,7 @@ __device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit
     const int len = s.len[g], nb = (len + 15) >> 4;
     const float* dr = s.D + (long)brow * s.ldd + s.d_col0[g];
     const float* wr = s.W + (long)urow * s.ldw + s.w_col0[g];
+    const f32x4 before = acc;
     for (int j0 = wave; j0 < nb; j0 += BW_NW * BW_CH) {
       float4 av[BW_CH], bv[BW_CH];
 #pragma unroll
@@ -86,6 +87,16 @@ __device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i].w, acc, 0, 0, 0);
       }
     }
+    if (s.oscale[g] != nullptr) {
+      // this segment's product times its own mask (Keras implementation 1: the consumer read h * mask_g through gate g's columns of
+      // its recurrent kernel); C/D map: this lane holds rows 4 lq + r of column li
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int br = b0 + 4 * lq + r, un = unit0 + li;
+        const float m = (br < B && un < n_units) ? s.oscale[g][(long)br * s.oscale_ld + un] : 0.f;
+        acc[r] = before[r] + (acc[r] - before[r]) * m;
+      }
+    }
   }
   return acc;
 }
@@ -93,14 +104,13 @@ __device__ __forceinline__ f32x4 back_partial(const BackSrc& s, int b0, int unit
 // Element-wise part of one backward step for the (batch row b, unit j) pair, from the two matrix-product sums.
 struct BwdOperands {
   bool m;
-  float carry, svv[4], cpv, cov, dcv, hpv, addAv, addBv, dirv, rm;
+  float carry, svv[4], cpv, cov, dcv, hpv, addAv, addBv, dirv;
 };
 
 template <int CELL>
 __device__ __forceinline__ void load_bwd_operands(const Bwd2Dir& d, int b, int j, int H, bool linear, BwdOperands& o) {
   constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
   o.m = true; o.carry = 0.f; o.cpv = 0.f; o.cov = 0.f; o.dcv = 0.f; o.hpv = 0.f; o.addAv = 0.f; o.addBv = 0.f; o.dirv = 0.f;
-  o.rm = d.rmult ? d.rmult[(long)b * d.rmult_ld + j] : 1.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) o.svv[g] = 0.f;
   if (d.addA) o.addAv = d.addA[(long)b * d.addA_ld + j];
@@ -126,10 +136,9 @@ __device__ __forceinline__ void bwd_finish(const Bwd2Dir& d, const uint32_t* see
                                            float sa, float sb) {
   constexpr int NSV = CELL == CELL_RNN ? 1 : 4;
   const bool m = op.m;
-  // recurrent dropout (rm != 1): the consumer read h * rm through its recurrent kernel, and the GRU carry is z * (h_prev * rm)
-  const float rm = op.rm;
-  sa *= rm;
-  const float carry = op.carry, cpv = op.cpv, cov = op.cov, dcv = op.dcv, hpv = op.hpv * rm, addAv = op.addAv, addBv = op.addBv, dirv = op.dirv;
+  // (recurrent dropout: `sa` arrives with the per-gate masks applied by back_partial; the GRU carry z * h_prev takes the unmasked
+  // state - Keras implementation 1, which its cells use whenever recurrent_dropout != 0)
+  const float carry = op.carry, cpv = op.cpv, cov = op.cov, dcv = op.dcv, hpv = op.hpv, addAv = op.addAv, addBv = op.addBv, dirv = op.dirv;
   const float* svv = op.svv;
   struct { const uint32_t* seed; } a{seed};
   if (d.src[1].D != nullptr && d.src[1].drop_rate > 0.f) {
@@ -167,7 +176,7 @@ __device__ __forceinline__ void bwd_finish(const Bwd2Dir& d, const uint32_t* see
       ds[1] = dahh * arh * r * (1.f - r);
       ds[2] = dahh;
       ds[3] = dahh * r;
-      dir = dh * z * rm;
+      dir = dh * z;
     } else {
       const float hn = svv[0];
       ds[0] = dh * (1.f - hn * hn);
@@ -604,7 +613,7 @@ static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st)
       cols = c > cols ? c : cols;
     }
   bool rmult = false;                                            // recurrent dropout: narrow kernel only
-  for (int i = 0; i < ndir; ++i) rmult = rmult || a.d[i].rmult != nullptr;
+  for (int i = 0; i < ndir; ++i) rmult = rmult || a.d[i].src[0].oscale[0] != nullptr;
   if (wide && !rmult && nu >= min_h && a.B > 16 && (cols >= 2048 || min_h < 512)) {
     bool two = false;
     for (int i = 0; i < ndir; ++i) two = two || a.d[i].src[1].D != nullptr;
@@ -743,7 +752,21 @@ extern "C" int asr_rnn_seq_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* gs,
       if (sb.n_units > 0) {
         int rc = fill_dir(&a.d[d], &sb, s->rnn_type, nullptr);
         if (rc) return rc;
-        a.d[d].rmult = s->rec_mult[d]; a.d[d].rmult_ld = H;
+        if (s->rec_mult[d] && a.d[d].src[0].D) {
+          // recurrent dropout: one mask per gate ([NG][B,H] tables) on the state the consumer read - one column segment per gate
+          BackSrc& r = a.d[d].src[0];
+          const long gsz = (long)B * H;
+          if (s->rnn_type == CELL_GRU) {                     // ds slots z, r, (x-part), h~ ; recurrent kernel columns z, r, h~
+            r.nseg = 3;
+            r.d_col0[0] = 0; r.w_col0[0] = 0; r.d_col0[1] = H; r.w_col0[1] = H; r.d_col0[2] = 3 * H; r.w_col0[2] = 2 * H;
+          } else {
+            r.nseg = NG;
+            for (int g = 0; g < NG; ++g) { r.d_col0[g] = g * H; r.w_col0[g] = g * H; }
+          }
+          for (int g = 0; g < r.nseg; ++g) { r.len[g] = H; r.oscale[g] = s->rec_mult[d] + g * gsz; }
+          r.oscale_ld = H;
+          r.vec = r.vec && H % 4 == 0;
+        }
         any = true;
       } else {
         a.d[d] = Bwd2Dir{};   // n_units == 0: every thread of that direction exits as a non-owner

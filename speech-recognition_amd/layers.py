@@ -253,7 +253,9 @@ class BiRNN:
             dd = dict(pre=f(B, T, NG[rt] * H), hseq=f(B, T, H), mtab=f(B, self.Din), direct=f(B, H),
                       dy_carry=f(B, H), dh0=f(B, H), reverse=(d == 1), cell=self.cells[d])
             if self.recurrent_dropout > 0:
-                dd["rtab"] = f(B, H)
+                # Keras implementation 1 (forced by recurrent_dropout != 0): one mask per gate on h_tm1 AND on the input
+                dd["rtab"] = f(NG[rt], B, H)
+                dd["mtab_g"] = f(NG[rt], B, self.Din)
             dd["saved"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
             if rt == "lstm":
                 dd["cseq"] = f(B, T, H)
@@ -288,13 +290,23 @@ class BiRNN:
         for d, dd in enumerate(buf["dirs"]):
             p = self.store.p
             dd["rec_mult"] = None
-            if rdrop:
-                ops.dropout_table(dd["rtab"], seed, self.stream_rec + d, self.recurrent_dropout)
-                dd["rec_mult"] = dd["rtab"]
             W, b = p[self.names[d] + "kernel"], p[self.names[d] + "bias"]
-            if drop and not tables_ready:
-                ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
-            ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=(b[0] if rt == "gru" else b), a_scale=dd["mtab"] if drop else None, a_rpg=T)
+            bin_ = b[0] if rt == "gru" else b
+            if rdrop:
+                # [TF-sem] implementation 1: a mask per gate on the recurrent operand and (if dropout > 0) on the input; gate g's stream ids
+                # are the layer's + 128 g (rng.py); the input projection runs gate by gate, each with its own mask table
+                ng = NG[rt]
+                ops.dropout_tables([(dd["rtab"][g], self.stream_rec + d + 128 * g, self.recurrent_dropout) for g in range(ng)] +
+                                   ([(dd["mtab_g"][g], self.stream_in + d + 128 * g, self.dropout) for g in range(ng)] if drop else []), seed)
+                dd["rec_mult"] = dd["rtab"]
+                pre2 = dd["pre"].view(B * T, -1)
+                for g in range(ng):
+                    ops.gemm(x2d, W[:, g * H:(g + 1) * H], pre2[:, g * H:(g + 1) * H], bias=bin_[g * H:(g + 1) * H],
+                             a_scale=dd["mtab_g"][g] if drop else None, a_rpg=T)
+            else:
+                if drop and not tables_ready:
+                    ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
+                ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=bin_, a_scale=dd["mtab"] if drop else None, a_rpg=T)
             dd["bias_rec"] = b[1] if rt == "gru" else None
             dd["U"] = p[self.names[d] + "recurrent_kernel"]
             if init_states is not None:
@@ -361,7 +373,40 @@ class BiRNN:
         x2d = buf["x3d"].reshape(B * T, self.Din)
         g, p = self.store.g, self.store.p
 
+        # recurrent dropout (Keras implementation 1): (ds slot, kernel column block, mask index) of every gate, input side and recurrent side
+        gate_in = [(k, k, k) for k in range(NG[rt])]
+        gate_rec = [(0, 0, 0), (1, 1, 1), (3, 2, 2)] if rt == "gru" else [(k, k, k) for k in range(NG[rt])]
+
+        def param_grads_per_gate():     # the same sums with one dropout mask per gate on x and on h_prev
+            for d, dd in enumerate(buf["dirs"]):
+                nm = self.names[d]
+                ds3 = dd[dskey]
+                ds2 = ds3.view(B * T, -1)
+                gW, gU, gb = g[nm + "kernel"], g[nm + "recurrent_kernel"], g[nm + "bias"]
+                hs = dd["hseq"]
+                for sl, cb, mi in gate_in:
+                    dsv = ds2[:, sl * H:(sl + 1) * H]
+                    ops.gemm(x2d, dsv, gW[:, cb * H:(cb + 1) * H], trans_a=True, accumulate=1, split_k=auto_split_k(self.Din, H, B * T),
+                             a_scale=dd["mtab_g"][mi] if buf["drop"] else None, a_rpg=T)
+                    ops.colsum(dsv, (gb[0] if rt == "gru" else gb)[cb * H:(cb + 1) * H])
+                for sl, cb, mi in gate_rec:
+                    dsg = ds3[:, :, sl * H:(sl + 1) * H]
+                    gUg = gU[:, cb * H:(cb + 1) * H]
+                    rt_ = dd["rtab"][mi]
+                    if T > 1:
+                        if dd["reverse"]:
+                            ops.gemm(hs[:, 1:], dsg[:, :T - 1], gUg, trans_a=True, accumulate=1, a_scale=rt_, a_rpg=T, a_scale_stride=H)
+                        else:
+                            ops.gemm(hs[:, :T - 1], dsg[:, 1:], gUg, trans_a=True, accumulate=1, a_scale=rt_, a_rpg=T, a_scale_stride=H)
+                    if dd["h0"] is not None:
+                        t0 = T - 1 if dd["reverse"] else 0
+                        ops.gemm(dd["h0"], dsg[:, t0], gUg, trans_a=True, accumulate=1, a_scale=rt_, a_rpg=1)
+                    if rt == "gru":
+                        ops.colsum(ds2[:, sl * H:(sl + 1) * H], gb[1][cb * H:(cb + 1) * H])
+
         def param_grads():      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
+            if buf["rdrop"]:
+                return param_grads_per_gate()
             for d, dd in enumerate(buf["dirs"]):
                 nm = self.names[d]
                 ds3 = dd[dskey]
@@ -370,20 +415,16 @@ class BiRNN:
                 cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, None if pws is not None else g[nm + "bias"], a_scale=mt, a_rpg=T)
                 # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
                 hs = dd["hseq"]
-                # recurrent dropout: the cell multiplied (h_prev * rtab[b]) into U - scale the stored states the same way
-                # (one table row per batch entry: rows-per-group T covers a whole [T-1, H] slab, the slab index picks the row)
-                rs = dict(a_scale=dd["rtab"], a_rpg=T, a_scale_stride=H) if buf["rdrop"] else {}
-                rs0 = dict(a_scale=dd["rtab"], a_rpg=1) if buf["rdrop"] else {}
                 for s0, d0, n in slot_cols(rt, H, "rec"):
                     gU = g[nm + "recurrent_kernel"][:, d0:d0 + n]
                     if T > 1:
                         if dd["reverse"]:
-                            ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs)
+                            ops.gemm(hs[:, 1:], ds3[:, :T - 1, s0:s0 + n], gU, trans_a=True, accumulate=1)
                         else:
-                            ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs)
+                            ops.gemm(hs[:, :T - 1], ds3[:, 1:, s0:s0 + n], gU, trans_a=True, accumulate=1)
                     if dd["h0"] is not None:
                         t0 = T - 1 if dd["reverse"] else 0
-                        ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1, **rs0)
+                        ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
 
         if overlap is not None:
             overlap.defer(param_grads)
@@ -391,7 +432,14 @@ class BiRNN:
             side.run(param_grads)
         else:
             param_grads()
-        if dx3d is not None:
+        if dx3d is not None and buf["rdrop"]:                     # one input mask per gate: dx = sum_g (ds_g W_g^T) (.) mask_g
+            for d, dd in enumerate(buf["dirs"]):
+                ds2 = dd[dskey].view(B * T, -1)
+                W = p[self.names[d] + "kernel"]
+                for k, (sl, cb, mi) in enumerate(gate_in):
+                    ops.gemm(ds2[:, sl * H:(sl + 1) * H], W[:, cb * H:(cb + 1) * H], dx3d.view(B * T, self.Din), trans_b=True,
+                             accumulate=1 if (dx_accumulate or d == 1 or k > 0) else 0, c_scale=dd["mtab_g"][mi] if buf["drop"] else None, c_rpg=T)
+        elif dx3d is not None:
             for d, dd in enumerate(buf["dirs"]):
                 mt = dd["mtab"] if buf["drop"] else None
                 cell_input_grad(rt, H, dd[dskey].view(B * T, -1), p[self.names[d] + "kernel"], dx3d.view(B * T, self.Din),

@@ -584,9 +584,14 @@ class LAS(ModelProto):
         """Per backward segment, the gradient buckets that are complete when it ends.  With the overlap scheduler a stage's weight
         gradients run beside the NEXT stage's sweep, so every bucket completes one segment later and the last two together."""
         n = 2 + self.Le
-        if not self._ov.on:
-            return [[k] for k in range(n)]
-        return [[]] + [[k] for k in range(n - 2)] + [[n - 2, n - 1]]
+        if self._ov.on:
+            return [[]] + [[k] for k in range(n - 2)] + [[n - 2, n - 1]]
+        # The vocabulary bucket (complete after segment 0) is held back until the decoder segment has been enqueued: the decoder's
+        # backward sweep is one workgroup per compute unit at the register limit - an RCCL kernel that is resident when it starts keeps
+        # some of its workgroups off the chip until the collective has finished (the start handshake waits, sweep_common.h: safe, but
+        # serialised).  Behind the decoder segment both decoder-side buckets travel while the encoder sweeps run, which keep a
+        # quarter of the chip free (asr_sweep_capacity)
+        return [[], [0, 1]] + [[k] for k in range(2, n)]
 
     def backward_vocab(self, ws):
         """Vocabulary projection (las.py:291): its weight gradient and the gradient flowing into the decoder chain."""

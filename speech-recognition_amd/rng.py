@@ -12,6 +12,8 @@ STREAM_SPECAUG = 3         # data.py:282-301 draws, index = clip*64 + draw
 STREAM_TEACHER = 4         # las.py:366 one coin per batch
 STREAM_ENC_IN = 10         # + 2*layer + direction : Keras RNN input dropout, index over [B, Din]
 STREAM_ENC_REC = 60        # + 2*layer + direction : recurrent dropout, index over [B, H]
+# recurrent_dropout != 0 puts the Keras cells into implementation 1 - one mask PER GATE on both operands: gate g of a layer draws from
+# STREAM_ENC_IN / STREAM_ENC_REC + 2*layer + direction + 128*g (g = 0 is the single-mask stream)
 STREAM_DEC = 1000          # + 32*step + {0: embedding dropout, 1: output dropout, 2+j: decoder layer j input dropout}
 DEC_STREAMS_PER_STEP = 32
 MAX_DECODER_LAYERS = DEC_STREAMS_PER_STEP - 2

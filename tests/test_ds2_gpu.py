@@ -75,8 +75,9 @@ def test_ds2_inference_logits(rt, mask_mode):
     assert_close(out, ref, 2e-4, f"ds2 logits {rt} {mask_mode}")
 
 
-# recurrent_dropout > 0 (deepspeech2.py:95-107 passes it to the Keras cells): one [B,H] multiplier per direction on h_tm1,
-# constant over time, also inside the GRU's z * h_tm1 carry; hidden_dim 16 would otherwise take the persistent launches
+# recurrent_dropout > 0 (deepspeech2.py:95-107 passes it to the Keras cells, which then run their implementation 1): one [B,H] multiplier
+# PER GATE on h_tm1 and one [B,Din] multiplier per gate on the input, constant over time; the GRU's z * h_tm1 carry takes the unmasked
+# state; hidden_dim 16 would otherwise take the persistent launches
 @pytest.mark.parametrize("rt,dropout,rdrop,H", [("gru", 0.1, 0.0, 5), ("lstm", 0.1, 0.0, 5), ("rnn", 0.0, 0.0, 5),
                                                  ("gru", 0.1, 0.3, 5), ("lstm", 0.0, 0.25, 16), ("rnn", 0.1, 0.2, 5), ("gru", 0.0, 0.3, 16)])
 def test_ds2_training_step_loss_and_every_gradient(rt, dropout, rdrop, H):
