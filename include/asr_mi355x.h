@@ -146,6 +146,14 @@ int asr_fill_f32(float* p, long n, float value, void* stream);
 int asr_frame_mask(const float* x, int B, int T, int FC, int group, int Tout, uint8_t* out, void* stream);
 /* out[c] += sum_r A[r][c]  (bias gradients; atomic) */
 int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream);
+/* Mixed precision with bf16 operands IN MEMORY (the wide models, BASELINE configs[4]): C[M,N] (+)= alpha A[M,K] B[N,K]^T (+ bias) from bf16 images
+ * of both operands, k-contiguous (desc->trans_a = 0, trans_b = 1; lda / ldb / K multiples of 8), f32 accumulation and C, the epilogue options
+ * of asr_gemm_f32 except a_scale (fold it into the image).  asr_f32_to_bf16_image makes the images: dst[r][c] (transpose: dst[c][r]) =
+ * bf16(src[r][c] * scale[r / rows_per_group][c]); source row r = batch r / rows_per_batch (stride batch_stride) x row r % rows_per_batch
+ * (rows_per_batch 0 = one batch), so that the shifted [B, T-1, H] views of the recurrent-kernel gradient flatten into one product. */
+int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream);
+int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
+                          int rows_per_group, int transpose, void* dst, long ld_dst, void* stream);
 /* The one-column products of the hoisted attention (las.py:46-59: query_weight bias): out[c] += sum_r w[r] A[r][c] (d bq = K^T ds0),
  * y[r] = A[r][:] . x (s0 = K bq), C[r][c] += u[r] v[c] (the ds0 (x) bq term of dK) - memory-bound kernels instead of N = 1 / K = 1 GEMMs. */
 int asr_colsum_weighted(const float* A, int M, int N, long lda, const float* w, float* out, void* stream);

@@ -1,0 +1,207 @@
+// asr_gemm_bf16_nt: C[M,N] (+)= alpha * A[M,K] * B[N,K]^T (+ bias) with bf16 OPERANDS IN MEMORY, f32 accumulation and an f32 C -
+// the dense contractions of the wide models under --mixed-precision (run/train.py:62-66; BASELINE configs[4] las_large).
+//
+// Why a second GEMM: gemm_core.h's BF = 1 mode keeps f32 operands in memory and LDS and rounds them to bf16 as fragments leave
+// LDS - right for models whose activations must stay f32 for the f32 kernels around the product, but the staging then moves
+// four bytes per operand element through global -> register -> LDS -> register for a two-byte MFMA operand: 300-420 TFLOP/s on
+// the las_large shapes against a 2.5 PFLOP/s pipe.  Here both operands arrive as bf16 images, k-contiguous
+// ("NT": A rows and B rows both run along K), so that a lane's 16-byte LDS read IS its MFMA operand (8 consecutive k):
+//   v_mfma_f32_32x32x16_bf16: A lane l = (row l & 31, k 8 (l >> 5) .. + 7), B likewise with the column; C col = l & 31,
+//   row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+// Tile 128 x 128 x 64, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles; global -> registers -> LDS staging with the next
+// tile's loads in flight during the MFMAs (as gemm_core.h); LDS rows of 64 bf16 = 128 B, the 16-byte chunk index XORed with
+// (row & 7) so that the 32 rows a half-wave reads at one k offset fall on different banks.
+// The images are produced by memory-bound conversion passes (f32 -> bf16, optionally times the Keras input-dropout row-group
+// table, optionally TRANSPOSED: the weight-gradient products contract over the rows of both activations): ~0.1 ms per
+// 31936 x 2048 activation against ~1-3 ms of product saved.  Epilogue = gemm_core.h's (bias, ReLU, row-group scale, +=, atomics).
+#include "gemm_core.h"
+
+typedef unsigned short bf16_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+#define G16_BM 128
+#define G16_BN 128
+#define G16_BK 64
+
+__device__ __forceinline__ int g16_off(int row, int ch) { return row * 128 + 16 * (ch ^ (row & 7)); }   // byte offset of chunk ch (8 bf16) of a tile row
+
+__global__ __launch_bounds__(256) void gemm16_nt_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, GemmEpilogue ep, int M, int N, int K,
+                                                        int tiles_m, int tiles_n, int split_k, int k_chunk, long sAz, long sBz, long sCz) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[G16_BM * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[G16_BN * 128];
+  const int z = blockIdx.z / split_k, zs = blockIdx.z % split_k;
+  A += (long)z * sAz; B += (long)z * sBz; ep.C += (long)z * sCz;
+  if (zs != 0 || (z != 0 && sCz == 0)) ep.bias = nullptr;
+  const int kbeg = zs * k_chunk, kend = min(K, kbeg + k_chunk);
+  if (kbeg >= K) return;
+  // XCD-aware tile order (gemm.hip): blocks b, b + 8 share an XCD; every XCD walks a contiguous range, the smaller operand fastest
+  const int total = tiles_m * tiles_n;
+  const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+  const int p = xcd * (total >> 3) + min(xcd, total & 7) + idx;
+  const int bm = p / tiles_n, bn = p - bm * tiles_n;
+  const int m0 = bm * G16_BM, n0 = bn * G16_BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // staging: thread -> 4 chunks of A and 4 of B per K tile: chunk f = tid + 256 i -> (row f / 8, chunk f % 8)
+  u32x4_t ra[4], rb[4];
+  const int srow = tid >> 3, sch = tid & 7;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i, k = k0 + 8 * sch;
+      const int ma = m0 + r, nb = n0 + r;
+      ra[i] = (u32x4_t){0u, 0u, 0u, 0u};
+      rb[i] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (ma < M && k < kend) ra[i] = *reinterpret_cast<const u32x4_t*>(A + (long)ma * lda + k);     // (K, kbeg multiples of 8: whole chunks)
+      if (nb < N && k < kend) rb[i] = *reinterpret_cast<const u32x4_t*>(B + (long)nb * ldb + k);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i;
+      *reinterpret_cast<u32x4_t*>(As + g16_off(r, sch)) = ra[i];
+      *reinterpret_cast<u32x4_t*>(Bs + g16_off(r, sch)) = rb[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + G16_BK - 1) / G16_BK;
+  gload(kbeg);
+  for (int kt = 0; kt < nk; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload(kbeg + (kt + 1) * G16_BK);
+#pragma unroll
+    for (int s = 0; s < G16_BK / 16; ++s) {              // MFMA k-step s: this lane's 8 k = chunk 2 s + lh
+      bf16x8 a8[2], b8[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        a8[i] = *reinterpret_cast<const bf16x8*>(As + g16_off(m, 2 * s + lh));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + l31;
+        b8[j] = *reinterpret_cast<const bf16x8*>(Bs + g16_off(n, 2 * s + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const long srow2 = ep.map_row(row);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ep.put(row, srow2, n0 + wn * 64 + j * 32 + l31, acc[i][j][r]);
+    }
+}
+
+extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream) {
+  ASR_CHECK(d && A16 && B16 && C, ASR_ERR_ARG, "asr_gemm_bf16_nt: null argument");
+  ASR_CHECK(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, ASR_ERR_SHAPE, "asr_gemm_bf16_nt: bad M/N/K/batch %d %d %d %d", d->M, d->N, d->K, d->batch);
+  ASR_CHECK(!d->trans_a && d->trans_b, ASR_ERR_ARG, "asr_gemm_bf16_nt: operands must be k-contiguous (trans_a = 0, trans_b = 1): A [M,K], B [N,K]");
+  ASR_CHECK(d->K % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && ((uintptr_t)A16 & 15) == 0 && ((uintptr_t)B16 & 15) == 0 &&
+                d->stride_a % 8 == 0 && d->stride_b % 8 == 0,
+            ASR_ERR_SHAPE, "asr_gemm_bf16_nt: K, leading dimensions and batch strides must be multiples of 8 elements, operands 16-byte aligned");
+  ASR_CHECK(d->lda >= d->K && d->ldb >= d->K && d->ldc >= d->N, ASR_ERR_SHAPE, "asr_gemm_bf16_nt: leading dimension smaller than the row length");
+  ASR_CHECK(!d->a_scale, ASR_ERR_ARG, "asr_gemm_bf16_nt: fold the A row-group scale into the bf16 image (asr_f32_to_bf16_image)");
+  ASR_CHECK(!(d->c_scale && d->c_rpg <= 0), ASR_ERR_ARG, "asr_gemm_bf16_nt: group scale needs rows-per-group > 0");
+  const int sk = d->split_k > 1 ? d->split_k : 1;
+  ASR_CHECK(!(sk > 1 && !d->accumulate), ASR_ERR_ARG, "asr_gemm_bf16_nt: split_k > 1 accumulates atomically: set accumulate and pre-zero C");
+  ASR_CHECK((long)d->batch * sk <= 65535, ASR_ERR_SHAPE, "asr_gemm_bf16_nt: batch * split_k > 65535");
+  int mode = d->accumulate ? 1 : 0;
+  if (d->batch > 1 && d->stride_c == 0) {
+    ASR_CHECK(d->accumulate, ASR_ERR_ARG, "asr_gemm_bf16_nt: batch > 1 with stride_c == 0 (split-K over the batch) requires accumulate = 1");
+    mode = 2;
+  }
+  if (d->accumulate == 2 || sk > 1) mode = 2;
+  GemmEpilogue ep{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
+  const int tm = asr_cdiv(d->M, G16_BM), tn = asr_cdiv(d->N, G16_BN);
+  int k_chunk = asr_cdiv(asr_cdiv(d->K, sk), G16_BK) * G16_BK;
+  if (k_chunk <= 0) k_chunk = G16_BK;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * sk));
+  hipLaunchKernelGGL(gemm16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t*>(A16), d->lda, static_cast<const bf16_t*>(B16),
+                     d->ldb, ep, d->M, d->N, d->K, tm, tn, sk, k_chunk, d->stride_a, d->stride_b, d->stride_c);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ bf16 images of f32 operands
+// Source row r of a (possibly 3-D) operand: batch r / rpb at stride bstr, row r % rpb at stride lds (rpb = R: plain 2-D).
+// dst[r][c] = bf16(src[r][c] * scale[(r / rpg)][c])   (scale optional: the Keras RNN input-dropout table, one row per `rpg` source rows)
+__global__ __launch_bounds__(256) void bf16_image_kernel(const float* src, long lds, int R, int Cc, int rpb, long bstr, const float* scale, int rpg,
+                                                         bf16_t* dst, long ldd) {
+  const long n4 = Cc >> 2, total = (long)R * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / n4, c = (i % n4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + (r / rpb) * bstr + (r % rpb) * lds + c);
+    if (scale) {
+      const float4 s = *reinterpret_cast<const float4*>(scale + (r / rpg) * Cc + c);
+      v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+    }
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = o;
+  }
+}
+// dst[c][r] = bf16(src[r][c] * scale[(r / rpg)][c]): 64 x 64 tiles through LDS, coalesced on both sides
+__global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, long lds, int R, int Cc, int rpb, long bstr, const float* scale, int rpg,
+                                                           bf16_t* dst, long ldd) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cc) {
+      v = src[(long)(r / rpb) * bstr + (long)(r % rpb) * lds + c];
+      if (scale) v *= scale[(long)(r / rpg) * Cc + c];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) {
+      const __bf16 b = (__bf16)tile[tx][i];
+      dst[(long)c * ldd + r] = __builtin_bit_cast(bf16_t, b);
+    }
+  }
+}
+extern "C" int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
+                                     int rows_per_group, int transpose, void* dst, long ld_dst, void* stream) {
+  ASR_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols, ASR_ERR_ARG, "asr_f32_to_bf16_image: bad argument");
+  const int rpb = rows_per_batch > 0 ? rows_per_batch : rows;
+  ASR_CHECK(!(scale && rows_per_group <= 0), ASR_ERR_ARG, "asr_f32_to_bf16_image: scale needs rows_per_group > 0");
+  ASR_CHECK(ld_dst >= (transpose ? rows : cols), ASR_ERR_SHAPE, "asr_f32_to_bf16_image: destination rows too short");
+  hipStream_t st = (hipStream_t)stream;
+  if (transpose) {
+    hipLaunchKernelGGL(bf16_image_t_kernel, dim3((unsigned)asr_cdiv(cols, 64), (unsigned)asr_cdiv(rows, 64)), dim3(256), 0, st, src, ld_src, rows, cols, rpb,
+                       batch_stride, scale, rows_per_group, static_cast<bf16_t*>(dst), ld_dst);
+  } else {
+    ASR_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && batch_stride % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 &&
+                  (!scale || ((uintptr_t)scale & 15) == 0),
+              ASR_ERR_SHAPE, "asr_f32_to_bf16_image: the straight image needs columns / leading dimensions in multiples of 4 and aligned buffers");
+    const long total = (long)rows * (cols >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bf16_image_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, rows, cols, rpb, batch_stride, scale, rows_per_group,
+                       static_cast<bf16_t*>(dst), ld_dst);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

@@ -323,8 +323,98 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     d.c_scale = c_scale.data_ptr() if c_scale is not None else None
     d.c_rpg = int(c_rpg)
     d.compute = _compute["gemm"] if compute is None else int(compute)
+    if d.compute == 1 and _bf16_images["on"] and _gemm_bf16_images(d, a, b, c, trans_a, trans_b, a_scale, a_rpg, a_scale_stride):
+        return c
     check(lib().asr_gemm_f32(C.byref(d), _p(a), _p(b), _p(c), _stream()))
     return c
+
+
+# bf16 operand images for the large products under mixed precision (csrc/gemm16.hip): both operands are rewritten as k-contiguous
+# bf16 matrices by a memory-bound pass, then multiplied by the bf16-operand kernel.  Pays when every dimension is large (the wide
+# models); the small products keep the f32-operand kernel (whose fragments are rounded to bf16 on the way out of LDS: same numerics).
+_bf16_images = {"on": os.environ.get("ASR_GEMM_BF16_IMAGES", "1") != "0", "min_dim": int(os.environ.get("ASR_GEMM_BF16_MIN", "512")),
+                "scratch": {}}
+
+
+def _image_scratch(role, rows, cols):
+    """bf16 [rows, cols8] scratch, one per (role, stream, shape): GEMMs of one stream run in order, so consecutive products may
+    share it; products on different streams never do."""
+    cols8 = (cols + 7) // 8 * 8
+    key = (role, torch.cuda.current_stream().cuda_stream, rows, cols8)
+    buf = _bf16_images["scratch"].get(key)
+    if buf is None:
+        # zero-filled once: the k padding [cols, cols8) is never written by the image pass and must read as 0
+        buf = _bf16_images["scratch"][key] = torch.zeros(rows, cols8, device="cuda", dtype=torch.bfloat16)
+    return buf
+
+
+def f32_to_bf16_image(src, dst, *, transpose=False, scale=None, rows_per_group=0):
+    """dst (bf16 [rows, >= cols] or, transposed, [cols, >= rows]) = bf16(src * scale[row / rows_per_group]).  src: f32 2-D with unit
+    inner stride, or 3-D [batch, rows, cols] (flattened row-major over (batch, row))."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.stride(-1) == 1 and dst.stride(-1) == 1
+    if src.dim() == 3:
+        rows, rpb, bstr = src.shape[0] * src.shape[1], src.shape[1], src.stride(0)
+    else:
+        rows, rpb, bstr = src.shape[0], 0, 0
+    check(lib().asr_f32_to_bf16_image(_p(src), src.stride(-2), rows, src.shape[-1], rpb, bstr, _p(scale) if scale is not None else None,
+                                      int(rows_per_group), int(transpose), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream()))
+    return dst
+
+
+def gemm_bf16_nt(a16, b16, c, *, alpha=1.0, accumulate=0, bias=None, relu=False, c_scale=None, c_rpg=0, split_k=1, K=None):
+    """c [M,N] (+)= alpha * a16 [M,K] @ b16 [N,K]^T (+ bias): bf16 operands in memory, f32 accumulation (asr_gemm_bf16_nt)."""
+    assert a16.dtype == torch.bfloat16 and b16.dtype == torch.bfloat16 and c.dtype == torch.float32
+    d = _lib.GemmDesc()
+    d.trans_a, d.trans_b = 0, 1
+    d.M, d.N, d.K, d.batch = a16.shape[0], b16.shape[0], int(K if K is not None else a16.shape[1]), 1
+    d.split_k = int(split_k)
+    d.lda, d.ldb, d.ldc = a16.stride(0), b16.stride(0), c.stride(0)
+    d.alpha, d.accumulate, d.relu = alpha, int(accumulate), int(relu)
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.c_scale = c_scale.data_ptr() if c_scale is not None else None
+    d.c_rpg = int(c_rpg)
+    d.compute = 1
+    check(lib().asr_gemm_bf16_nt(C.byref(d), C.c_void_p(a16.data_ptr()), C.c_void_p(b16.data_ptr()), _p(c), _stream()))
+    return c
+
+
+def _gemm_bf16_images(d, a, b, c, trans_a, trans_b, a_scale, a_rpg, a_scale_stride):
+    """Route one product through bf16 images if it qualifies; returns False (nothing done) otherwise."""
+    md = _bf16_images["min_dim"]
+    flat = a.dim() == 3 and b.dim() == 3 and c.dim() == 2 and trans_a and not trans_b          # split-K over the batch: one long K
+    if a.dim() != b.dim() or (a.dim() == 3 and not flat) or c.dim() != 2:
+        return False
+    K = d.K * d.batch if flat else d.K
+    if d.M < md // 2 or d.N < md // 2 or K < md or d.M * d.N < md * md:
+        return False
+    if a.stride(-1) != 1 or b.stride(-1) != 1 or c.stride(-1) != 1:
+        return False
+    K8 = (K + 7) // 8 * 8
+    scale, rpg = a_scale, a_rpg
+    if flat and a_scale is not None:
+        if a_scale_stride != a.shape[-1] or a_rpg < a.shape[1]:
+            return False
+        rpg = a.shape[1]                                          # one scale row per batch
+    # straight images read float4s
+    for t, tr in ((a, trans_a), (b, not trans_b)):
+        if not tr and (t.shape[-1] % 4 or t.stride(-2) % 4 or t.data_ptr() % 16):
+            return False
+    if not trans_a and scale is not None and scale.data_ptr() % 16:
+        return False
+    a16 = f32_to_bf16_image(a, _image_scratch("a", d.M, K8), transpose=trans_a, scale=scale, rows_per_group=rpg)
+    b16 = f32_to_bf16_image(b, _image_scratch("b", d.N, K8), transpose=not trans_b)
+    acc = 1 if d.accumulate else 0                                # (the batch split became one product: no atomics needed)
+    if d.split_k > 1:
+        acc = 2
+    d2 = _lib.GemmDesc()
+    d2.trans_a, d2.trans_b = 0, 1
+    d2.M, d2.N, d2.K, d2.batch = d.M, d.N, K8, 1
+    d2.split_k = d.split_k
+    d2.lda, d2.ldb, d2.ldc = a16.stride(0), b16.stride(0), c.stride(0)
+    d2.alpha, d2.accumulate, d2.relu = d.alpha, acc, d.relu
+    d2.bias, d2.c_scale, d2.c_rpg, d2.compute = d.bias, d.c_scale, d.c_rpg, 1
+    check(lib().asr_gemm_bf16_nt(C.byref(d2), C.c_void_p(a16.data_ptr()), C.c_void_p(b16.data_ptr()), _p(c), _stream()))
+    return True
 
 
 def bf16_to_f32(src: torch.Tensor, dst: torch.Tensor):

@@ -1,0 +1,106 @@
+"""The bf16-operand product (csrc/gemm16.hip) and the image passes feeding it, against the float64 product of the bf16-rounded
+operands: the only difference allowed is f32 accumulation order.  Shapes cover ragged M/N tiles, K that is no multiple of 8
+(zero-padded image columns), every operand layout ops.gemm routes (NN, NT, TN, batch-flattened TN), and the epilogue options."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def _check(got, want, a, b):
+    # f32 accumulation of K products: error << sqrt(K) * eps_f32 * |a|.|b|; 1e-4 of the output scale is loose for that and tight for
+    # a wrong element (a missing k chunk, a misplaced tile)
+    scale = float(want.abs().max())
+    err = float((got.double() - want).abs().max())
+    assert err <= 1e-4 * scale, (err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 520, 1001), (1024, 384, 2048), (130, 4100, 776)])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_routed_product_matches_f64_of_rounded_operands(M, N, K, layout):
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    Bm = torch.randn(K, N, generator=g).cuda()
+    ta, tb = layout[0] == "t", layout[1] == "t"
+    a = A.t().contiguous() if ta else A
+    b = Bm.t().contiguous() if tb else Bm
+    bias = torch.randn(N, generator=g).cuda()
+    c = torch.empty(M, N, device="cuda")
+    old = ops._bf16_images["min_dim"]
+    ops._bf16_images["min_dim"] = 128
+    try:
+        before = len(ops._bf16_images["scratch"])
+        ops.gemm(a, b, c, trans_a=ta, trans_b=tb, bias=bias, compute=1)
+        assert len(ops._bf16_images["scratch"]) > before or before > 0, "the bf16-image path must be the one under test"
+        want = _bf(A) @ _bf(Bm) + bias.double()
+        _check(c, want, A, Bm)
+        # accumulate + alpha + relu
+        c2 = torch.ones(M, N, device="cuda")
+        ops.gemm(a, b, c2, trans_a=ta, trans_b=tb, alpha=0.5, accumulate=1, compute=1)
+        _check(c2, 0.5 * (_bf(A) @ _bf(Bm)) + 1.0, A, Bm)
+        ops.gemm(a, b, c, trans_a=ta, trans_b=tb, relu=True, compute=1)
+        _check(c, torch.relu(_bf(A) @ _bf(Bm)), A, Bm)
+    finally:
+        ops._bf16_images["min_dim"] = old
+
+
+def test_row_group_scale_is_folded_into_the_image():
+    """Keras input dropout: one multiplier row per sequence (a_rpg = T rows), applied to the f32 values BEFORE the bf16 rounding,
+    as the f32-operand kernel does."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Bq, T, D, N = 6, 50, 256, 384
+    x = torch.randn(Bq * T, D, generator=g).cuda()
+    W = torch.randn(D, N, generator=g).cuda()
+    tab = (torch.rand(Bq, D, generator=g) > 0.3).float().cuda() / 0.7
+    old = ops._bf16_images["min_dim"]
+    ops._bf16_images["min_dim"] = 128
+    try:
+        c = torch.empty(Bq * T, N, device="cuda")
+        ops.gemm(x, W, c, a_scale=tab, a_rpg=T, compute=1)
+        xs = (x.view(Bq, T, D) * tab[:, None]).view(Bq * T, D)
+        _check(c, _bf(xs) @ _bf(W), xs, W)
+        # weight gradient: x^T ds with the same table on the stored rows of x
+        ds = torch.randn(Bq * T, N, generator=g).cuda()
+        gW = torch.zeros(D, N, device="cuda")
+        ops.gemm(x, ds, gW, trans_a=True, accumulate=1, a_scale=tab, a_rpg=T, compute=1)
+        _check(gW, _bf(xs).t() @ _bf(ds), xs, ds)
+    finally:
+        ops._bf16_images["min_dim"] = old
+
+
+def test_batch_split_flattens_into_one_long_k():
+    """dU = sum_b h[b, :T-1]^T ds[b, 1:] (the shifted views of the recurrent-kernel gradient): 3-D operands, 2-D c."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(7)
+    Bq, T, H, N = 5, 41, 256, 512
+    hs = torch.randn(Bq, T, H, generator=g).cuda()
+    ds = torch.randn(Bq, T, N, generator=g).cuda()
+    old = ops._bf16_images["min_dim"]
+    ops._bf16_images["min_dim"] = 128
+    try:
+        gU = torch.zeros(H, N, device="cuda")
+        ops.gemm(hs[:, :T - 1], ds[:, 1:], gU, trans_a=True, accumulate=1, compute=1)
+        want = torch.einsum("bth,btn->hn", _bf(hs[:, :T - 1]), _bf(ds[:, 1:]))
+        _check(gU, want, hs, ds)
+        ops.gemm(hs[:, 1:], ds[:, :T - 1, 128:384], gU[:, 128:384], trans_a=True, accumulate=1, compute=1)      # column slices
+        want[:, 128:384] += torch.einsum("bth,btn->hn", _bf(hs[:, 1:]), _bf(ds[:, :T - 1, 128:384]))
+        _check(gU, want, hs, ds)
+    finally:
+        ops._bf16_images["min_dim"] = old
+
+
+def test_small_products_keep_the_f32_operand_kernel():
+    from speech_recognition_amd import ops
+    a = torch.randn(64, 96).cuda()
+    b = torch.randn(96, 80).cuda()
+    c = torch.empty(64, 80, device="cuda")
+    n = len(ops._bf16_images["scratch"])
+    ops.gemm(a, b, c, compute=1)
+    assert len(ops._bf16_images["scratch"]) == n
+    _check(c, _bf(a) @ _bf(b), a, b)
