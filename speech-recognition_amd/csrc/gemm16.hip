@@ -14,21 +14,27 @@
 // The images are produced by memory-bound conversion passes (f32 -> bf16, optionally times the Keras input-dropout row-group
 // table, optionally TRANSPOSED: the weight-gradient products contract over the rows of both activations): ~0.1 ms per
 // 31936 x 2048 activation against ~1-3 ms of product saved.  Epilogue = gemm_core.h's (bias, ReLU, row-group scale, +=, atomics).
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 typedef unsigned short bf16_t;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
-#define G16_BM 128
-#define G16_BN 128
 #define G16_BK 64
 
 __device__ __forceinline__ int g16_off(int row, int ch) { return row * 128 + 16 * (ch ^ (row & 7)); }   // byte offset of chunk ch (8 bf16) of a tile row
 
-__global__ __launch_bounds__(256) void gemm16_nt_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, GemmEpilogue ep, int M, int N, int K,
-                                                        int tiles_m, int tiles_n, int split_k, int k_chunk, long sAz, long sBz, long sCz) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[G16_BM * 128];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[G16_BN * 128];
+// WM x WN waves, each TM x TN MFMA tiles of 32 x 32: block tile (32 WM TM) x (32 WN TN) x 64.  NBUF LDS buffers: with 2 the tile for step
+// kt + 1 is written into the other buffer BEFORE the MFMAs of step kt and the loads of tile kt + 2 are issued right after (one barrier per
+// K step, loads in flight for a whole MFMA phase); with 1 the write waits behind the MFMAs (two barriers, half the LDS: more blocks per CU).
+template <int WM, int WN, int TM, int TN, int NBUF>
+__global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, GemmEpilogue ep, int M, int N, int K,
+                                                                 int tiles_m, int tiles_n, int split_k, int k_chunk, long sAz, long sBz, long sCz) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
+  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;             // 16-byte chunks per thread and K tile
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging map");
+  extern __shared__ __attribute__((aligned(16))) unsigned char g16_smem[];
   const int z = blockIdx.z / split_k, zs = blockIdx.z % split_k;
   A += (long)z * sAz; B += (long)z * sBz; ep.C += (long)z * sCz;
   if (zs != 0 || (z != 0 && sCz == 0)) ep.bias = nullptr;
@@ -39,76 +45,115 @@ __global__ __launch_bounds__(256) void gemm16_nt_kernel(const bf16_t* A, long ld
   const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
   const int p = xcd * (total >> 3) + min(xcd, total & 7) + idx;
   const int bm = p / tiles_n, bn = p - bm * tiles_n;
-  const int m0 = bm * G16_BM, n0 = bn * G16_BN;
+  const int m0 = bm * BM, n0 = bn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  // staging: thread -> 4 chunks of A and 4 of B per K tile: chunk f = tid + 256 i -> (row f / 8, chunk f % 8)
-  u32x4_t ra[4], rb[4];
+  // staging: chunk f = tid + NT i -> (row f / 8, chunk f % 8): 8 consecutive lanes cover one 128-byte row segment
+  u32x4_t ra[CA], rb[CB];
   const int srow = tid >> 3, sch = tid & 7;
   auto gload = [&](int k0) {
+    const int k = k0 + 8 * sch;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i, k = k0 + 8 * sch;
-      const int ma = m0 + r, nb = n0 + r;
+    for (int i = 0; i < CA; ++i) {
+      const int ma = m0 + srow + (NT / 8) * i;
       ra[i] = (u32x4_t){0u, 0u, 0u, 0u};
-      rb[i] = (u32x4_t){0u, 0u, 0u, 0u};
       if (ma < M && k < kend) ra[i] = *reinterpret_cast<const u32x4_t*>(A + (long)ma * lda + k);     // (K, kbeg multiples of 8: whole chunks)
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int nb = n0 + srow + (NT / 8) * i;
+      rb[i] = (u32x4_t){0u, 0u, 0u, 0u};
       if (nb < N && k < kend) rb[i] = *reinterpret_cast<const u32x4_t*>(B + (long)nb * ldb + k);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    unsigned char* As = g16_smem + buf * (BM + BN) * 128;
+    unsigned char* Bs = As + BM * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = srow + 32 * i;
-      *reinterpret_cast<u32x4_t*>(As + g16_off(r, sch)) = ra[i];
-      *reinterpret_cast<u32x4_t*>(Bs + g16_off(r, sch)) = rb[i];
-    }
+    for (int i = 0; i < CA; ++i) *reinterpret_cast<u32x4_t*>(As + g16_off(srow + (NT / 8) * i, sch)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) *reinterpret_cast<u32x4_t*>(Bs + g16_off(srow + (NT / 8) * i, sch)) = rb[i];
   };
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto compute = [&](int buf) {
+    const unsigned char* As = g16_smem + buf * (BM + BN) * 128;
+    const unsigned char* Bs = As + BM * 128;
+#pragma unroll
+    for (int s = 0; s < G16_BK / 16; ++s) {              // MFMA k-step s: this lane's 8 k = chunk 2 s + lh
+      bf16x8 a8[TM], b8[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a8[i] = *reinterpret_cast<const bf16x8*>(As + g16_off((wm * TM + i) * 32 + l31, 2 * s + lh));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b8[j] = *reinterpret_cast<const bf16x8*>(Bs + g16_off((wn * TN + j) * 32 + l31, 2 * s + lh));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    }
+  };
 
   const int nk = (kend - kbeg + G16_BK - 1) / G16_BK;
   gload(kbeg);
-  for (int kt = 0; kt < nk; ++kt) {
-    lstore();
+  if constexpr (NBUF == 2) {
+    lstore(0);
+    if (nk > 1) gload(kbeg + G16_BK);
     __syncthreads();
-    if (kt + 1 < nk) gload(kbeg + (kt + 1) * G16_BK);
-#pragma unroll
-    for (int s = 0; s < G16_BK / 16; ++s) {              // MFMA k-step s: this lane's 8 k = chunk 2 s + lh
-      bf16x8 a8[2], b8[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = wm * 64 + i * 32 + l31;
-        a8[i] = *reinterpret_cast<const bf16x8*>(As + g16_off(m, 2 * s + lh));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = wn * 64 + j * 32 + l31;
-        b8[j] = *reinterpret_cast<const bf16x8*>(Bs + g16_off(n, 2 * s + lh));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) lstore((kt + 1) & 1);
+      if (kt + 2 < nk) gload(kbeg + (kt + 2) * G16_BK);
+      compute(kt & 1);
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      lstore(0);
+      __syncthreads();
+      if (kt + 1 < nk) gload(kbeg + (kt + 1) * G16_BK);
+      compute(0);
+      __syncthreads();
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const long srow2 = ep.map_row(row);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) ep.put(row, srow2, n0 + wn * 64 + j * 32 + l31, acc[i][j][r]);
+      for (int j = 0; j < TN; ++j) ep.put(row, srow2, n0 + (wn * TN + j) * 32 + l31, acc[i][j][r]);
     }
+}
+
+struct G16Launch {
+  const bf16_t *A, *B; GemmEpilogue ep; const asr_gemm_desc* d; int sk; hipStream_t st;
+};
+template <int WM, int WN, int TM, int TN, int NBUF>
+static void g16_launch(const G16Launch& g) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr size_t smem = (size_t)NBUF * (BM + BN) * 128;
+  auto kern = gemm16_nt_kernel<WM, WN, TM, TN, NBUF>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  const asr_gemm_desc* d = g.d;
+  const int tm = asr_cdiv(d->M, BM), tn = asr_cdiv(d->N, BN);
+  int k_chunk = asr_cdiv(asr_cdiv(d->K, g.sk), G16_BK) * G16_BK;
+  if (k_chunk <= 0) k_chunk = G16_BK;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * g.sk));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, g.st, g.A, d->lda, g.B, d->ldb, g.ep, d->M, d->N, d->K, tm, tn, g.sk, k_chunk, d->stride_a,
+                     d->stride_b, d->stride_c);
+}
+static int g16_config() {
+  static int c = -1;
+  if (c < 0) { const char* e = getenv("ASR_G16_CFG"); c = e ? atoi(e) : 0; }
+  return c;
 }
 
 extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream) {
@@ -131,12 +176,13 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
   }
   if (d->accumulate == 2 || sk > 1) mode = 2;
   GemmEpilogue ep{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
-  const int tm = asr_cdiv(d->M, G16_BM), tn = asr_cdiv(d->N, G16_BN);
-  int k_chunk = asr_cdiv(asr_cdiv(d->K, sk), G16_BK) * G16_BK;
-  if (k_chunk <= 0) k_chunk = G16_BK;
-  dim3 grid((unsigned)(tm * tn), 1, (unsigned)(d->batch * sk));
-  hipLaunchKernelGGL(gemm16_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const bf16_t*>(A16), d->lda, static_cast<const bf16_t*>(B16),
-                     d->ldb, ep, d->M, d->N, d->K, tm, tn, sk, k_chunk, d->stride_a, d->stride_b, d->stride_c);
+  const G16Launch g{static_cast<const bf16_t*>(A16), static_cast<const bf16_t*>(B16), ep, d, sk, (hipStream_t)stream};
+  switch (g16_config()) {                                       // (measured on the las_large products: within 5 % of each other; the
+    case 1: g16_launch<2, 2, 2, 2, 2>(g); break;                 //  single-buffered 128 x 128 tile keeps three blocks per CU resident)
+    case 2: g16_launch<4, 2, 2, 2, 2>(g); break;                 // 256 x 128, 8 waves
+    case 3: g16_launch<4, 2, 2, 2, 1>(g); break;
+    default: g16_launch<2, 2, 2, 2, 1>(g); break;                // 128 x 128, 4 waves, one LDS buffer
+  }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -159,7 +205,8 @@ __global__ __launch_bounds__(256) void bf16_image_kernel(const float* src, long 
     *reinterpret_cast<bf16x4*>(dst + r * ldd + c) = o;
   }
 }
-// dst[c][r] = bf16(src[r][c] * scale[(r / rpg)][c]): 64 x 64 tiles through LDS, coalesced on both sides
+// dst[c][r] = bf16(src[r][c] * scale[(r / rpg)][c]): 64 x 64 tiles through LDS, coalesced on both sides.  (A 128 x 64 tile written as packed
+// bf16 pairs measured 1.5x SLOWER - 4-way LDS conflicts on the paired read and half the blocks in flight; this pass runs at ~3.1 TB/s.)
 __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, long lds, int R, int Cc, int rpb, long bstr, const float* scale, int rpg,
                                                            bf16_t* dst, long ldd) {
   __shared__ float tile[64][65];

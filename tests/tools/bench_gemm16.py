@@ -34,3 +34,15 @@ for on in (False, True):
     ops._bf16_images["on"] = on
     t = tm(lambda: ops.gemm(hs[:, :T - 1], ds[:, 1:], gU, trans_a=True, accumulate=1, compute=1))
     print(f"dU batch-flattened images={on}: {t:.3f} ms ({2.0*H*4*H*B*(T-1)/t/1e9:.0f} TF)", flush=True)
+# the pieces alone
+ops._bf16_images["on"] = True
+x = torch.randn(R, D, device="cuda"); W = torch.randn(D, G, device="cuda"); dsb = torch.randn(R, G, device="cuda")
+x16 = torch.zeros(R, D, device="cuda", dtype=torch.bfloat16); w16 = torch.zeros(G, D, device="cuda", dtype=torch.bfloat16)
+xt16 = torch.zeros(D, R, device="cuda", dtype=torch.bfloat16); dst16 = torch.zeros(G, R, device="cuda", dtype=torch.bfloat16)
+c = torch.zeros(R, G, device="cuda"); gW = torch.zeros(D, G, device="cuda")
+print(f"image x straight [R,2048]      {tm(lambda: ops.f32_to_bf16_image(x, x16)):.3f} ms")
+print(f"image W transposed [2048,4096] {tm(lambda: ops.f32_to_bf16_image(W, w16, transpose=True)):.3f} ms")
+print(f"image x transposed [R,2048]    {tm(lambda: ops.f32_to_bf16_image(x, xt16, transpose=True)):.3f} ms")
+print(f"image ds transposed [R,4096]   {tm(lambda: ops.f32_to_bf16_image(dsb, dst16, transpose=True)):.3f} ms")
+t = tm(lambda: ops.gemm_bf16_nt(x16, w16, c)); print(f"gemm16 fwd alone  {t:.3f} ms ({2.0*R*D*G/t/1e9:.0f} TF)")
+t = tm(lambda: ops.gemm_bf16_nt(xt16, dst16, gW)); print(f"gemm16 dW alone   {t:.3f} ms ({2.0*R*D*G/t/1e9:.0f} TF)")
