@@ -28,7 +28,10 @@ __device__ __forceinline__ int g16_off(int row, int ch) { return row * 128 + 16 
 // WM x WN waves, each TM x TN MFMA tiles of 32 x 32: block tile (32 WM TM) x (32 WN TN) x 64.  NBUF LDS buffers: with 2 the tile for step
 // kt + 1 is written into the other buffer BEFORE the MFMAs of step kt and the loads of tile kt + 2 are issued right after (one barrier per
 // K step, loads in flight for a whole MFMA phase); with 1 the write waits behind the MFMAs (two barriers, half the LDS: more blocks per CU).
-template <int WM, int WN, int TM, int TN, int NBUF>
+// STG 1: the tiles go global -> LDS directly (global_load_lds_dwordx4: a wave instruction fills 8 tile rows = 1024 contiguous bytes, the XOR
+// swizzle applied to the per-lane SOURCE chunk) - no staging registers, no ds_write pass; needs whole K tiles (K, k_chunk multiples of 64) and
+// clamps out-of-range rows to the last valid one (the epilogue drops them).
+template <int WM, int WN, int TM, int TN, int NBUF, int STG>
 __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, GemmEpilogue ep, int M, int N, int K,
                                                                  int tiles_m, int tiles_n, int split_k, int k_chunk, long sAz, long sBz, long sCz) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
@@ -101,8 +104,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
   };
 
   const int nk = (kend - kbeg + G16_BK - 1) / G16_BK;
-  gload(kbeg);
-  if constexpr (NBUF == 2) {
+  if constexpr (STG == 1) {
+    constexpr int NW = WM * WN;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "glds map");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;             // dest row within its 8-row group, SOURCE chunk for dest position lane & 7
+    auto stage = [&](int k0, int buf) {
+      unsigned char* As = g16_smem + buf * (BM + BN) * 128;
+      unsigned char* Bs = As + BM * 128;
+#pragma unroll
+      for (int i = 0; i < BM / 8 / NW; ++i) {
+        const int g = wave + NW * i;
+        const int ma = min(m0 + 8 * g + r8, M - 1);
+        __builtin_amdgcn_global_load_lds(A + (long)ma * lda + k0 + 8 * c8, (lds_ptr_t)(As + g * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 8 / NW; ++i) {
+        const int g = wave + NW * i;
+        const int nb = min(n0 + 8 * g + r8, N - 1);
+        __builtin_amdgcn_global_load_lds(B + (long)nb * ldb + k0 + 8 * c8, (lds_ptr_t)(Bs + g * 1024), 16, 0, 0);
+      }
+    };
+    if constexpr (NBUF == 2) {
+      stage(kbeg, 0);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // tile kt landed for everyone; everyone is done with compute(kt - 1)
+        if (kt + 1 < nk) stage(kbeg + (kt + 1) * G16_BK, (kt + 1) & 1);
+        compute(kt & 1);
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        stage(kbeg + kt * G16_BK, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute(0);
+        __syncthreads();
+      }
+    }
+  } else if constexpr (NBUF == 2) {
+    gload(kbeg);
     lstore(0);
     if (nk > 1) gload(kbeg + G16_BK);
     __syncthreads();
@@ -113,6 +154,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
       __syncthreads();
     }
   } else {
+    gload(kbeg);
     for (int kt = 0; kt < nk; ++kt) {
       lstore(0);
       __syncthreads();
@@ -135,11 +177,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
 struct G16Launch {
   const bf16_t *A, *B; GemmEpilogue ep; const asr_gemm_desc* d; int sk; hipStream_t st;
 };
-template <int WM, int WN, int TM, int TN, int NBUF>
+template <int WM, int WN, int TM, int TN, int NBUF, int STG>
 static void g16_launch(const G16Launch& g) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr size_t smem = (size_t)NBUF * (BM + BN) * 128;
-  auto kern = gemm16_nt_kernel<WM, WN, TM, TN, NBUF>;
+  auto kern = gemm16_nt_kernel<WM, WN, TM, TN, NBUF, STG>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   const asr_gemm_desc* d = g.d;
@@ -150,10 +192,15 @@ static void g16_launch(const G16Launch& g) {
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, g.st, g.A, d->lda, g.B, d->ldb, g.ep, d->M, d->N, d->K, tm, tn, g.sk, k_chunk, d->stride_a,
                      d->stride_b, d->stride_c);
 }
+static int g16_cfg = -1;
 static int g16_config() {
-  static int c = -1;
-  if (c < 0) { const char* e = getenv("ASR_G16_CFG"); c = e ? atoi(e) : 0; }
-  return c;
+  if (g16_cfg < 0) { const char* e = getenv("ASR_G16_CFG"); g16_cfg = e ? atoi(e) : 0; }
+  return g16_cfg;
+}
+extern "C" int asr_gemm_bf16_config(int cfg) {                   // tuning / tests: select the tile configuration (-1: leave), returns the previous one
+  const int old = g16_config();
+  if (cfg >= 0) g16_cfg = cfg;
+  return old;
 }
 
 extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream) {
@@ -177,11 +224,18 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
   if (d->accumulate == 2 || sk > 1) mode = 2;
   GemmEpilogue ep{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
   const G16Launch g{static_cast<const bf16_t*>(A16), static_cast<const bf16_t*>(B16), ep, d, sk, (hipStream_t)stream};
-  switch (g16_config()) {                                       // (measured on the las_large products: within 5 % of each other; the
-    case 1: g16_launch<2, 2, 2, 2, 2>(g); break;                 //  single-buffered 128 x 128 tile keeps three blocks per CU resident)
-    case 2: g16_launch<4, 2, 2, 2, 2>(g); break;                 // 256 x 128, 8 waves
-    case 3: g16_launch<4, 2, 2, 2, 1>(g); break;
-    default: g16_launch<2, 2, 2, 2, 1>(g); break;                // 128 x 128, 4 waves, one LDS buffer
+  const bool whole = d->K % G16_BK == 0;                        // (k_chunk is a multiple of 64 by construction)
+  int cfg = g16_config();
+  if (!whole && cfg >= 4) cfg = 0;
+  switch (cfg) {
+    case 1: g16_launch<2, 2, 2, 2, 2, 0>(g); break;
+    case 2: g16_launch<4, 2, 2, 2, 2, 0>(g); break;              // 256 x 128, 8 waves
+    case 3: g16_launch<4, 2, 2, 2, 1, 0>(g); break;
+    case 4: g16_launch<2, 2, 2, 2, 1, 1>(g); break;              // direct-to-LDS staging
+    case 5: g16_launch<2, 2, 2, 2, 2, 1>(g); break;
+    case 6: g16_launch<4, 2, 2, 2, 1, 1>(g); break;
+    case 7: g16_launch<4, 2, 2, 2, 2, 1>(g); break;
+    default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;

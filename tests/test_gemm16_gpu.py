@@ -19,9 +19,18 @@ def _check(got, want, a, b):
     assert err <= 1e-4 * scale, (err, scale)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 520, 1001), (1024, 384, 2048), (130, 4100, 776)])
+@pytest.fixture(params=range(8))
+def tile_config(request):
+    """Every tile configuration of the kernel (register / direct-to-LDS staging, one / two LDS buffers, 128 / 256-row tiles)."""
+    from speech_recognition_amd import ops
+    old = ops.lib().asr_gemm_bf16_config(request.param)
+    yield request.param
+    ops.lib().asr_gemm_bf16_config(old)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (300, 520, 1001), (1024, 384, 2048), (130, 4100, 776), (1000, 700, 1088)])
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
-def test_routed_product_matches_f64_of_rounded_operands(M, N, K, layout):
+def test_routed_product_matches_f64_of_rounded_operands(M, N, K, layout, tile_config):
     from speech_recognition_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).cuda()

@@ -80,3 +80,50 @@ for name, gemm in GEMMS.items():
             ev1.record(s2)
         torch.cuda.synchronize()
         print(f"   beside {bname}: gemm {ev0.elapsed_time(ev1) * 1e3:.1f} us; background {b0.elapsed_time(b1) * 1e3:.1f} us (alone {t_bg:.1f})", flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- CU-masked streams
+# The sweep on a stream confined to one set of compute units, the GEMM on a stream confined to the complement: no CU is shared, what
+# is left of the interference is L2 / fabric / HBM.  Masks are tried two ways because the bit -> (XCD, CU) map is the runtime's business.
+import ctypes
+
+_hip = ctypes.CDLL("libamdhip64.so")
+
+
+def masked_stream(words):
+    s = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    rc = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(s), len(words), arr)
+    assert rc == 0, f"hipExtStreamCreateWithCUMask -> {rc}"
+    return torch.cuda.ExternalStream(s.value)
+
+
+MASKS = {"low/high halves": ([0xFFFFFFFF] * 4 + [0] * 4, [0] * 4 + [0xFFFFFFFF] * 4),
+         "even/odd bits": ([0x55555555] * 8, [0xAAAAAAAA] * 8),
+         "even/odd bytes": ([0x00FF00FF] * 8, [0xFF00FF00] * 8),
+         "192 / 64": ([0xFFFFFFFF] * 6 + [0] * 2, [0] * 6 + [0xFFFFFFFF] * 2)}
+for mname, (ma, mb) in MASKS.items():
+    sa, sb = masked_stream(ma), masked_stream(mb)
+    torch.cuda.synchronize()
+    t_sw = timed(sweep, sa, 3)
+    print(f"masks {mname}: sweep alone on its CUs {t_sw:.1f} us", flush=True)
+    for name, gemm in GEMMS.items():
+        t_g = timed(gemm, sb)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(sa):
+            b0.record(sa)
+            sweep()
+            b1.record(sa)
+        with torch.cuda.stream(sb):
+            ops.sweep_gate(ops.sweep_diag_words(pws), 300)
+            ev0.record(sb)
+            for _ in range(6):
+                gemm()
+            ev1.record(sb)
+        torch.cuda.synchronize()
+        print(f"   {name}: alone on its CUs {t_g:.1f} us; 6 beside the sweep {ev0.elapsed_time(ev1) * 1e3 / 6:.1f} us each, sweep {b0.elapsed_time(b1) * 1e3:.1f} us",
+              flush=True)
+    diag = ops.sweep_diagnosis(pws, "rnn_sweep_bwd", clear=True) if hasattr(ops, "sweep_diagnosis") else None
+    print(f"   diagnosis: {diag}", flush=True)
