@@ -33,9 +33,10 @@
 // Wave roles (512 threads).  gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave with
 // write-through stores in flight cannot consume a later load before their acknowledgements are back:
 //   waves 0-3  GATHER + OWNER: poll the G blocks, add them up (registers, then LDS), gate-gradient math of the 16 x KU (row, unit)
-//              pairs, ds to LDS (and, in column j = 0 of the square, to `saved`);
+//              pairs from the forward sweep's coefficient packs, ds to LDS;
 //   waves 4-7  PUBLISH: multiply ds with the resident block of U^T (contraction split over the waves, summed through LDS),
-//              publish the [16 x KU] block, re-arm the block of two steps ago.  They never load from global memory.
+//              publish the [16 x KU] block, re-arm the block of three steps ago, write ds out of place (column j = 0 of the square) and
+//              sum the bias gradients.  They never load from global memory.
 // The roles hand over through LDS counters (a workgroup barrier would make the gather waves wait for store
 // acknowledgements); LDS buffers are double-buffered by step parity and protected by causality through the exchange
 // (a gather of step p+2 cannot complete before this workgroup's own publish of step p+1).
