@@ -434,6 +434,14 @@ int asr_sweep_gate(const float* diag_words, int max_microseconds, void* stream);
 int asr_rnn_sweep_wide_supported(int rnn_type, int B, int T, int H, int ndir);
 long asr_rnn_sweep_wide_ws_floats(int B, int H, int ndir);
 int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* err_flag, void* stream);
+/* The same layer's backward-through-time in one launch (models/las.py:90-106 differentiated; csrc/rnn_sweep_wide_bwd.hip): a 32 x 4 grid of
+ * workgroups per direction with resident bf16 blocks of the recurrent kernel exchanges bf16 partial sums of dh.  Contract of
+ * asr_rnn_sweep_bwd, except: reads s->saved / s->cseq (not coefficient packs), writes g->ds out of place (must not alias s->saved),
+ * ignores g->db.  LSTM, H = 1024, B <= 64, 128 * ndir <= compute units.  ws: asr_rnn_sweep_wide_bwd_ws_floats() floats (48 MB exchange
+ * for two directions + the 32 diagnosis words). */
+int asr_rnn_sweep_wide_bwd_supported(int rnn_type, int B, int T, int H, int ndir);
+long asr_rnn_sweep_wide_bwd_ws_floats(int B, int H, int ndir);
+int asr_rnn_sweep_wide_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g, float* ws, float* err_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One-launch forward sweep of the LAS decoder under teacher forcing (las.py:267-292 looped by las.py:368-377): all U steps of

@@ -175,6 +175,9 @@ SIGNATURES = {
     "asr_rnn_sweep_wide_supported": (C.c_int, [C.c_int] * 5),
     "asr_rnn_sweep_wide_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
     "asr_rnn_sweep_wide_fwd": (C.c_int, [C.POINTER(RnnSeq), _P, _P, _P]),
+    "asr_rnn_sweep_wide_bwd_supported": (C.c_int, [C.c_int] * 5),
+    "asr_rnn_sweep_wide_bwd_ws_floats": (c_long, [C.c_int, C.c_int, C.c_int]),
+    "asr_rnn_sweep_wide_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P, _P, _P]),
     "asr_decoder_sweep_supported": (C.c_int, [C.c_int] * 7),
     "asr_decoder_sweep_ws_floats": (c_long, [C.c_int, C.c_int]),
     "asr_decoder_sweep_fwd": (C.c_int, [C.POINTER(DecoderSweep), _P, _P, _P]),

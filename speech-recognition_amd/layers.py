@@ -18,6 +18,7 @@ import os
 
 # ASR_PERSISTENT_RNN=0 forces the one-launch-per-step recurrent kernels (debugging / A-B timing)
 PERSISTENT_RNN = os.environ.get("ASR_PERSISTENT_RNN", "1") != "0"
+WIDE_SWEEP_BWD = os.environ.get("ASR_WIDE_SWEEP_BWD", "1") != "0"  # the wide layers' BPTT as one launch (rnn_sweep_wide_bwd.hip)
 WIDE_SWEEP = os.environ.get("ASR_WIDE_SWEEP", "1") != "0"      # the bf16 weights-resident forward sweep of wide layers (mixed precision)
 
 NG = {"lstm": 4, "gru": 3, "rnn": 1}   # gates in the Keras kernel layout
@@ -269,6 +270,14 @@ class BiRNN:
             for dd in buf["dirs"]:
                 dd["coef_buf"] = f(B, T, H * ops.rnn_coef_width(rt))
                 dd["ds"] = f(B, T, NS[rt] * H) if rt == "gru" else dd["pre"]
+        # wide layers under mixed precision: the BPTT sweep with resident bf16 blocks of U (rnn_sweep_wide_bwd.hip).  It reads the saved
+        # activations while it writes ds (the workgroups of a grid row repeat the gate gradients, each at its own pace): ds out of place
+        buf["wide_bwd_mode"] = bool(PERSISTENT_RNN and WIDE_SWEEP_BWD and self.recurrent_dropout == 0 and T >= 2 and not buf["coef_mode"]
+                                    and ops.rnn_sweep_wide_bwd_supported(rt, B, T, H, 2)
+                                    and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
+        if buf["wide_bwd_mode"]:
+            for dd in buf["dirs"]:
+                dd["ds"] = f(B, T, NS[rt] * H)
         return buf
 
     def final_states(self, buf):
@@ -354,6 +363,9 @@ class BiRNN:
             if "persist_bwd_ws" not in buf:
                 buf["persist_bwd_ws"] = ops.rnn_persist_bwd_ws(B, H, 2, dy3d.device)
             pws = buf["persist_bwd_ws"]
+        wide = bool(buf.get("wide_bwd_mode")) and not buf["rdrop"] and pws is None and ops.mixed_precision()
+        if wide and "wide_bwd_ws" not in buf:
+            buf["wide_bwd_ws"] = ops.rnn_sweep_wide_bwd_ws(B, H, 2, dy3d.device)
         gds = []
         for d, dd in enumerate(buf["dirs"]):
             if buf["mask"] is not None:
@@ -361,11 +373,14 @@ class BiRNN:
             gb = self.store.g[self.names[d] + "bias"]
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
                             dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"],
-                            ds=dd["ds"] if pws is not None else None,
+                            ds=dd["ds"] if (pws is not None or wide) else None,
                             # the BPTT sweep sums the bias gradients itself (no second pass over ds)
                             db=(gb[0] if rt == "gru" else gb) if pws is not None else None, db_rec=gb[1] if (rt == "gru" and pws is not None) else None))
-        dskey = "ds" if pws is not None else "saved"     # where this backward pass leaves the gate-sum gradients
-        sweep = lambda: ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
+        dskey = "ds" if (pws is not None or wide) else "saved"     # where this backward pass leaves the gate-sum gradients
+        if wide:
+            sweep = lambda: ops.rnn_sweep_wide_bwd(buf["seq"], dy3d, gds, buf["wide_bwd_ws"], getattr(self.store, "err_flag", None))
+        else:
+            sweep = lambda: ops.rnn_seq_bwd(buf["seq"], dy3d, gds, pws, getattr(self.store, "err_flag", None) if pws is not None else None)
         if overlap is not None:
             overlap.beside(sweep, ops.sweep_diag_words(pws) if pws is not None else None)
         else:

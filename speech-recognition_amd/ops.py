@@ -566,6 +566,39 @@ def rnn_sweep_wide_fwd(seq, ws, err_flag=None):
     check(lib().asr_rnn_sweep_wide_fwd(C.byref(seq), _p(ws), _p(err_flag), _stream()))
 
 
+def rnn_sweep_wide_bwd_supported(rnn_type, B, T, H, ndir=2) -> bool:
+    """True when the wide one-launch BPTT sweep (rnn_sweep_wide_bwd.hip: resident bf16 blocks of U, bf16 partial sums; mixed precision) takes
+    this layer."""
+    return mixed_precision() and bool(lib().asr_rnn_sweep_wide_bwd_supported(rnn_type_id(rnn_type), B, T, H, ndir))
+
+
+def rnn_sweep_wide_bwd_ws(B, H, ndir=2, device="cuda"):
+    return torch.zeros(int(lib().asr_rnn_sweep_wide_bwd_ws_floats(B, H, ndir)), device=device, dtype=torch.float32)
+
+
+def _rnn_seq_grad(dy, dirs_grad):
+    g = _lib.RnnSeqGrad()
+    g.dy = dy.data_ptr()
+    g.dy_ld = dy.stride(1)
+    g.dh_last = _arr2([d.get("dh_last") for d in dirs_grad])
+    g.dh_last_ld = _arr2([d["dh_last"].stride(0) if d.get("dh_last") is not None else 0 for d in dirs_grad], C.c_long)
+    g.dc = _arr2([d.get("dc") for d in dirs_grad])
+    g.dy_carry = _arr2([d.get("dy_carry") for d in dirs_grad])
+    g.direct = _arr2([d.get("direct") for d in dirs_grad])
+    g.dh0 = _arr2([d.get("dh0") for d in dirs_grad])
+    g.dh0_ld = _arr2([d["dh0"].stride(0) if d.get("dh0") is not None else 0 for d in dirs_grad], C.c_long)
+    g.ds = _arr2([d.get("ds") for d in dirs_grad])
+    g.db = _arr2([d.get("db") for d in dirs_grad])
+    g.db_rec = _arr2([d.get("db_rec") for d in dirs_grad])
+    return g
+
+
+def rnn_sweep_wide_bwd(seq, dy, dirs_grad, ws, err_flag=None):
+    """The wide layer's BPTT in one launch; dirs_grad as for rnn_seq_bwd, with `ds` [B,T,4H] tensors of their own (out)."""
+    g = _rnn_seq_grad(dy, dirs_grad)
+    check(lib().asr_rnn_sweep_wide_bwd(C.byref(seq), C.byref(g), _p(ws), _p(err_flag), _stream()))
+
+
 def rnn_persist_error(ws) -> int:
     """Non-zero if a hand-off of the last one-launch sweep timed out (synchronises): (who gave up | step << 8)."""
     return int(ws[-32:].view(torch.int32)[0].item())

@@ -116,7 +116,8 @@ def sweep_diagnoses(ws, clear=True):
         buf = lw.get("rnn") if isinstance(lw, dict) else None
         if not buf:
             continue
-        for key, kind in (("persist_ws", "rnn_sweep_fwd"), ("persist_bwd_ws", "rnn_sweep_bwd"), ("wide_ws", "rnn_sweep_wide")):
+        for key, kind in (("persist_ws", "rnn_sweep_fwd"), ("persist_bwd_ws", "rnn_sweep_bwd"), ("wide_ws", "rnn_sweep_wide"),
+                          ("wide_bwd_ws", "rnn_sweep_wide_bwd")):
             if key in buf:
                 d = ops.sweep_diagnosis(buf[key], kind, clear=clear)
                 if d:

@@ -64,8 +64,9 @@ class HipBiRNN:
                 states.append(dd["cseq"][:, t_last])
         return self.y, states
 
-    def backward(self, dy, dstates, persistent=False):
-        """dy [B,T,ndir*H]; dstates: list like the states list (or None entries). Returns dict of grads."""
+    def backward(self, dy, dstates, persistent=False, wide=False):
+        """dy [B,T,ndir*H]; dstates: list like the states list (or None entries). Returns dict of grads.
+        persistent: the f32 BPTT sweep (asr_rnn_sweep_bwd); wide: the wide layers' BPTT sweep (asr_rnn_sweep_wide_bwd)."""
         ops, B, T, H = self.ops, self.B, self.T, self.H
         nst = 2 if self.rt == "lstm" else 1
         gds = []
@@ -84,9 +85,19 @@ class HipBiRNN:
             pws = ops.rnn_persist_bwd_ws(B, H, len(self.dirs))
             for dd, g in zip(self.dirs, gds):                     # the sweep writes ds out of place, the step kernels over `saved`
                 g["ds"] = dd["ds"] = torch.empty_like(dd["saved"])
-        ops.rnn_seq_bwd(self.seq, gpu(dy), gds, pws)
-        if persistent:
-            assert not ops.rnn_persist_error(pws), "persistent backward: a hand-off timed out"
+        if wide:
+            assert ops.rnn_sweep_wide_bwd_supported(self.rt, B, T, H, len(self.dirs))
+            wws = ops.rnn_sweep_wide_bwd_ws(B, H, len(self.dirs))
+            for dd, g in zip(self.dirs, gds):
+                g["ds"] = dd["ds"] = torch.full_like(dd["saved"], float("nan"))
+            ops.rnn_sweep_wide_bwd(self.seq, gpu(dy), gds, wws)
+            torch.cuda.synchronize()
+            assert not ops.rnn_persist_error(wws), f"wide backward sweep: a hand-off timed out: {ops.sweep_diagnosis(wws, 'rnn_sweep_wide_bwd')}"
+            persistent = True                                     # (ds is in dd["ds"])
+        else:
+            ops.rnn_seq_bwd(self.seq, gpu(dy), gds, pws)
+            if persistent:
+                assert not ops.rnn_persist_error(pws), "persistent backward: a hand-off timed out"
         out = []
         for d, (dd, g) in enumerate(zip(self.dirs, gds)):
             W, U, b = [p.double() for p in self.params[d]]

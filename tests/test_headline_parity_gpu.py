@@ -202,7 +202,7 @@ def _bilstm_bf16_operands(x, fwd, bwd):
     return torch.cat(outs, -1)
 
 
-def test_las_large_layer_wide_sweep_and_staged_backward_at_full_sequence_geometry():
+def test_las_large_layer_wide_sweeps_and_staged_backward_at_full_sequence_geometry():
     """One BiLSTM layer at las_large's per-GPU batch and sequence length - B = 64, T' = 499 (20 s clips), H = 1024 - through
     rnn_sweepw_fwd_kernel (bf16 weights resident) and rnn_step_bwd_staged_kernel under mixed precision.  Forward against the
     oracle with bf16-rounded (h, U): 2e-3 of the largest entry (an h within rounding of a bf16 boundary may flip and moves the
@@ -232,16 +232,23 @@ def test_las_large_layer_wide_sweep_and_staged_backward_at_full_sequence_geometr
         assert_close(hip.y, y_r.detach(), 2e-3, "las_large layer outputs")
         assert not ops.rnn_persist_bwd_supported("lstm", B, T, H, 2), "H = 1024 is beyond the f32 BPTT sweep: the staged step kernels run"
         grads = hip.backward(dy, [None] * 4, persistent=False)
+        # the same layer through the one-launch wide BPTT sweep (rnn_sweepw_bwd_kernel: bf16 partial sums on top of the bf16 operands)
+        hip2 = HipBiRNN("lstm", x, None, fwd, bwd, None)
+        ops.rnn_sweep_wide_fwd(hip2.seq, wws)
+        grads_sweep = hip2.backward(dy, [None] * 4, wide=True)
     finally:
         ops.set_mixed_precision(False)
-    for d, (gr, lv) in enumerate(zip(grads, leaves)):
-        for key, ref in (("dW", lv[0].grad), ("dU", lv[1].grad), ("db", lv[2].grad)):
-            got = gr[key].double().cpu()
-            l2 = float((got - ref).norm()) / float(ref.norm())
-            assert l2 < 3e-2, f"direction {d} {key}: relative L2 error {l2:.2e}"
-    dx = sum(gr["dx"] for gr in grads).double().cpu()
-    l2 = float((dx - xr.grad).norm()) / float(xr.grad.norm())
-    assert l2 < 3e-2, f"dx: relative L2 error {l2:.2e}"
+    for name, grs in (("staged step kernels", grads), ("wide BPTT sweep", grads_sweep)):
+        for d, (gr, lv) in enumerate(zip(grs, leaves)):
+            for key, ref in (("dW", lv[0].grad), ("dU", lv[1].grad), ("db", lv[2].grad)):
+                got = gr[key].double().cpu()
+                l2 = float((got - ref).norm()) / float(ref.norm())
+                print(f"{name}: direction {d} {key}: relative L2 error {l2:.2e}")
+                assert l2 < 3e-2, f"{name}: direction {d} {key}: relative L2 error {l2:.2e}"
+        dx = sum(gr["dx"] for gr in grs).double().cpu()
+        l2 = float((dx - xr.grad).norm()) / float(xr.grad.norm())
+        print(f"{name}: dx: relative L2 error {l2:.2e}")
+        assert l2 < 3e-2, f"{name}: dx: relative L2 error {l2:.2e}"
 
 
 def test_las_large_yml_training_step_with_127_decoder_steps():

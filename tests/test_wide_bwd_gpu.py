@@ -1,0 +1,47 @@
+"""The wide layers' one-launch BPTT sweep (csrc/rnn_sweep_wide_bwd.hip; las_large: H = 1024 under mixed precision) against the per-step
+staged kernels it replaces, on the same saved activations: same bf16 operands (ds, U), f32 accumulation - the sweep additionally rounds the
+32 partial sums of every dh element to bf16 for the exchange, so the comparison is in relative L2 (1e-2 per tensor; measured up to 3e-3 on dh0 after 33 chained steps),
+not bit-exact.  Masks (ragged lengths incl. a fully padded tail), a ragged batch (rows >= B never stored), chained final-state
+gradients, initial states, both directions."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).norm()) / max(float(b.norm()), 1e-30)
+
+
+@pytest.mark.parametrize("B,T,masked,states", [(64, 12, False, False), (50, 9, True, True), (7, 33, True, False), (64, 3, False, True)])
+def test_wide_bwd_sweep_equals_the_staged_step_kernels(B, T, masked, states):
+    from speech_recognition_amd import ops
+    from tests.rnn_helpers import HipBiRNN
+    from tests.test_rnn_gpu import make_params
+    D, H = 48, 1024
+    g = torch.Generator().manual_seed(B * 100 + T)
+    fwd, bwd = make_params("lstm", D, H, g, 0.03)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    mask = None
+    if masked:
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        mask = torch.arange(T)[None, :] < lens[:, None]
+    init = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.3 for _ in range(4)] if states else None
+    dst = [torch.randn(B, H, generator=g, dtype=torch.float64) * 0.1 for _ in range(4)] if states else [None] * 4
+    dy = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64) * 0.05
+    ops.set_mixed_precision(True)
+    try:
+        outs = []
+        for wide in (False, True):
+            hip = HipBiRNN("lstm", x, mask, fwd, bwd, init)
+            hip.forward(persistent=False)
+            outs.append(hip.backward(dy, dst, wide=wide))
+    finally:
+        ops.set_mixed_precision(False)
+    for d in range(2):
+        ref, got = outs[0][d], outs[1][d]
+        for key in ("dW", "dU", "db", "dx", "dh0", "dc0"):
+            assert torch.isfinite(got[key]).all(), (d, key)
+            err = _rel(got[key], ref[key])
+            assert err < 1e-2, f"direction {d} {key}: relative L2 {err:.2e}"
