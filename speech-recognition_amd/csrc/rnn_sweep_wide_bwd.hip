@@ -11,7 +11,7 @@
 //   1. gathers, for ITS 32 units, the partial sums of all 32 workgroups (., j(i)) of the column block j(i) = i / 8 its units lie in:
 //      32 senders x [64 rows x 32 units] bf16 = 128 KB - the forward sweep's volume - and adds them up in f32: dh_t for its units;
 //   2. does the element-wise gate gradients of its (row, unit) pairs (4 per thread; the 4 workgroups of a grid row repeat them -
-//      cheaper than another hand-off) and leaves ds_t [64 x 128] as a bf16 image in LDS; column j = 0 also writes ds_t (f32) out;
+//      cheaper than another hand-off) and leaves ds_t [64 x 128] as a bf16 image in LDS; column j also writes gate j of ds_t (f32) out;
 //   3. multiplies: partial[256 units x 64 rows] = U[J_j, K_i] (resident bf16 A operands, 32 VGPRs per lane for the whole sequence)
 //      x ds_t^T (B operands from the LDS image) on v_mfma_f32_16x16x32_bf16 - the product is taken transposed so that a lane's
 //      accumulators are 4 consecutive units of ONE batch row and pack into the exchange piece without a transpose;
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
   const long dir_words = (long)blockIdx.z * WB_SLOTS * WB_SLOT_WORDS;
   // gather: column block jc = i / 8, slice i % 8 of every sender's block; this thread takes senders 16 sp .. 16 sp + 15, piece (row, q)
-  const long g_off = ((long)((gi >> 3) * WB_GI + 16 * sp) * 8 + (gi & 7)) * 1024 + (long)(row * 4 + q) * 4;
+  const long g_base = ((long)((gi >> 3) * WB_GI) * 8 + (gi & 7)) * 1024;                                   // words, wave-uniform
+  const long g_lane = (long)(16 * sp) * 8 * 1024 + (long)(row * 4 + q) * 4;                                // words, per lane
+  const unsigned g_voff = (unsigned)(g_lane * 4);                                                          // bytes
   // publish: block (column block j, sender i), slice = wave, piece (row = 16 nt + li, q = lq)
   const long p_off = ((long)(gj * WB_GI + gi) * 8 + wv) * 1024 + (long)(li * 4 + lq) * 4;
 
@@ -141,37 +143,41 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
     f32x4 dh = {0.f, 0.f, 0.f, 0.f};
     if (p > 0 && !abort_flag) {
       // ---------------------------------------------------------------------------------------- gather (32 senders, 16 per thread)
-      const uint32_t* src = a.xbuf + dir_words + (long)(p % WB_SLOTS) * WB_SLOT_WORDS + g_off;
+      const uint32_t* src0 = a.xbuf + dir_words + (long)(p % WB_SLOTS) * WB_SLOT_WORDS + g_base;      // wave-uniform
+      const uint32_t* src = src0 + g_lane;
+      // One probe piece until it is fresh (256 workgroups re-reading 128 KB each per retry would sit in front of the very publishes
+      // they wait for: issuing the whole gather first and probing only after a miss measured 11.8 against 9.9 us per step), then the
+      // whole gather, 16 loads per lane in flight.
       bool ok2 = true;
-      for (int spins = 0;; ++spins) {                              // one probe piece (the last sender of this thread's half) until fresh
-        u32x4 v;
-        const uint32_t* pp = src + 15l * 8 * 1024;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(pp) : "memory");
-        if (__all(wb_fresh(v)) || (a.dbg & 2)) break;
+      for (int sp2 = 0;; ++sp2) {
+        u32x4 pv;
+        const uint32_t* pp = src + 15l * 8 * 1024;                  // the last sender of this lane's half
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(pv) : "v"(pp) : "memory");
+        if (__all(wb_fresh(pv)) || (a.dbg & 2)) break;
         if (*(volatile int*)&abort_flag) { ok2 = false; break; }
-        if (spins > a.spin_limit) { abort_flag = 1 | (p << 8); ok2 = false; break; }
+        if (sp2 > a.spin_limit) { abort_flag = 1 | (p << 8); ok2 = false; break; }
         __builtin_amdgcn_s_sleep(4);
       }
       float acc8[8];
       for (int spins = 0; ok2; ++spins) {
+        u32x4 v[16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
+        for (int s16 = 0; s16 < 16; ++s16) {
+          // wave-uniform sender base in SGPRs + ONE 32-bit lane offset for all 16 loads
+          const uint32_t* sb = src0 + (long)s16 * 8 * 1024;
+          asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=&v"(v[s16]) : "v"(g_voff), "s"(sb) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]),
+                       "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])::"memory");
         bool ok = true;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          u32x4 v[8];
+        for (int e = 0; e < 8; ++e) acc8[e] = 0.f;
 #pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) {
-            const uint32_t* pp = src + (long)(8 * half + s8) * 8 * 1024;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v[s8]) : "v"(pp) : "memory");
-          }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) {
-            ok = ok && wb_fresh(v[s8]);
-            acc8[0] += wb_lo(v[s8].x); acc8[1] += wb_hi(v[s8].x); acc8[2] += wb_lo(v[s8].y); acc8[3] += wb_hi(v[s8].y);
-            acc8[4] += wb_lo(v[s8].z); acc8[5] += wb_hi(v[s8].z); acc8[6] += wb_lo(v[s8].w); acc8[7] += wb_hi(v[s8].w);
-          }
+        for (int s16 = 0; s16 < 16; ++s16) {
+          ok = ok && wb_fresh(v[s16]);
+          acc8[0] += wb_lo(v[s16].x); acc8[1] += wb_hi(v[s16].x); acc8[2] += wb_lo(v[s16].y); acc8[3] += wb_hi(v[s16].y);
+          acc8[4] += wb_lo(v[s16].z); acc8[5] += wb_hi(v[s16].z); acc8[6] += wb_lo(v[s16].w); acc8[7] += wb_hi(v[s16].w);
         }
         if (__all(ok) || (a.dbg & 2)) break;
         if (*(volatile int*)&abort_flag) { ok2 = false; break; }
@@ -225,11 +231,12 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
         *reinterpret_cast<bf16x4_t*>(im + wb_img(row, 4 * g + (ug >> 3)) + ((ug >> 2) & 1) * 8) = h;
       }
     }
-    if (live && writer && !(a.dbg & 16)) {
+    if (live && !(a.dbg & 16)) {
+      // the layer's ds: the four workgroups of a grid row hold the same values - column j stores gate j (one 16-byte store per lane;
+      // all four gates from column 0 made its 32 workgroups 1.9 us per step slower than the rest, and everybody waits for the slowest)
       const int s = T - 1 - p, t = d.reverse ? T - 1 - s : s;
-      float* o = d.ds + ((long)row * T + t) * 4 * H + j0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(o + (long)g * H) = ds[g];
+      float* o = d.ds + ((long)row * T + t) * 4 * H + (long)gj * H + j0;
+      *reinterpret_cast<f32x4*>(o) = gj == 0 ? ds[0] : (gj == 1 ? ds[1] : (gj == 2 ? ds[2] : ds[3]));
     }
     fetch(p + 1, op);                                              // next step's operands: in flight during the product and the next gather
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: the image is complete
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
                           wb_pack2(acc[1][nt][0], acc[1][nt][1]), wb_pack2(acc[1][nt][2], acc[1][nt][3])};
         __builtin_amdgcn_raw_buffer_store_b128(pc, rsrc, (int)((dst + nt * 256) * 4), 0, 16);       // aux 16 = sc1 (write-through)
       }
-      if (p >= 3 && !(a.dbg & 1)) {
+      if (p >= 3 && !(a.dbg & 1)) {      // (whole 16-byte pieces: re-arming one word per piece - enough for the freshness test - measured 0.65 us per step SLOWER)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((old + nt * 256) * 4), 0, 16);
       }

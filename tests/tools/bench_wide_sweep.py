@@ -22,3 +22,16 @@ t_w = time_fn(lambda: ops.rnn_sweep_wide_fwd(hip.seq, ws), 5)
 assert not ops.rnn_persist_error(ws) or os.environ.get("ASR_SWEEP_DBG"), "wide sweep timed out"
 t_s = time_fn(lambda: ops.rnn_seq_fwd(hip.seq), 3)
 print(f"B={B} T={T} H={H}: wide sweep {t_w:9.1f} us = {t_w / T:6.2f} us/step    step kernels {t_s:9.1f} us = {t_s / T:6.2f} us/step")
+# the backward sweep (rnn_sweep_wide_bwd.hip) against the staged step kernels
+dy = torch.randn(B, T, 2 * H, generator=g).cuda() * 0.05
+ops.rnn_seq_fwd(hip.seq)
+gds = [dict(direct=torch.zeros(B, H, device="cuda"), dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"),
+            dc=torch.zeros(B, H, device="cuda"), ds=torch.empty_like(dd["saved"])) for dd in hip.dirs]
+if ops.rnn_sweep_wide_bwd_supported("lstm", B, T, H, 2):
+    wb = ops.rnn_sweep_wide_bwd_ws(B, H, 2)
+    t_b = time_fn(lambda: ops.rnn_sweep_wide_bwd(hip.seq, dy, gds, wb), 5)
+    assert not ops.rnn_persist_error(wb) or os.environ.get("ASR_SWEEP_DBG"), f"wide backward sweep timed out: {ops.sweep_diagnosis(wb, 'rnn_sweep_wide_bwd')}"
+    print(f"B={B} T={T} H={H}: wide BPTT sweep {t_b:9.1f} us = {t_b / T:6.2f} us/step", flush=True)
+if not os.environ.get("ASR_SWEEP_DBG"):
+    t_s = time_fn(lambda: ops.rnn_seq_bwd(hip.seq, dy, gds), 2)
+    print(f"B={B} T={T} H={H}: staged step kernels {t_s:9.1f} us = {t_s / T:6.2f} us/step")
