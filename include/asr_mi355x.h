@@ -154,7 +154,10 @@ int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream)
 int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream);
 int asr_gemm_bf16_config(int cfg);   /* tile configuration of asr_gemm_bf16_nt (tuning and tests; -1 = query); returns the previous one */
 int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
-                          int rows_per_group, int transpose, void* dst, long ld_dst, void* stream);
+                          int rows_per_group, int transpose, void* dst, long ld_dst, int dst_rows_per_batch, int dst_shift, void* stream);
+/* (dst_rows_per_batch, dst_shift; transposed image only, 0 0 = off: source row r lands in destination column
+ *  (r / rows_per_batch) * dst_rows_per_batch + r % rows_per_batch + dst_shift - h[b, t] beside ds[b, t + 1] for the recurrent-kernel gradient,
+ *  which then shares the transposed ds image of the input-kernel gradient; the columns left out must already be zero.) */
 /* The one-column products of the hoisted attention (las.py:46-59: query_weight bias): out[c] += sum_r w[r] A[r][c] (d bq = K^T ds0),
  * y[r] = A[r][:] . x (s0 = K bq), C[r][c] += u[r] v[c] (the ds0 (x) bq term of dK) - memory-bound kernels instead of N = 1 / K = 1 GEMMs. */
 int asr_colsum_weighted(const float* A, int M, int N, long lda, const float* w, float* out, void* stream);

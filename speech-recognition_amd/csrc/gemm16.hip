@@ -261,8 +261,10 @@ __global__ __launch_bounds__(256) void bf16_image_kernel(const float* src, long 
 }
 // dst[c][r] = bf16(src[r][c] * scale[(r / rpg)][c]): 64 x 64 tiles through LDS, coalesced on both sides.  (A 128 x 64 tile written as packed
 // bf16 pairs measured 1.5x SLOWER - 4-way LDS conflicts on the paired read and half the blocks in flight; this pass runs at ~3.1 TB/s.)
+// Destination column of source row r: (r / rpb) * drpb + r % rpb + dshift - the batches of a 3-D source can land at a different pitch and
+// offset (the recurrent-kernel gradient pairs h[b, t -+ 1] with ds[b, t]: the shifted h image then shares ds's transposed image).
 __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, long lds, int R, int Cc, int rpb, long bstr, const float* scale, int rpg,
-                                                           bf16_t* dst, long ldd) {
+                                                           bf16_t* dst, long ldd, int drpb, int dshift) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -280,20 +282,23 @@ __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, lon
     const int c = c0 + i, r = r0 + tx;
     if (c < Cc && r < R) {
       const __bf16 b = (__bf16)tile[tx][i];
-      dst[(long)c * ldd + r] = __builtin_bit_cast(bf16_t, b);
+      dst[(long)c * ldd + (long)(r / rpb) * drpb + r % rpb + dshift] = __builtin_bit_cast(bf16_t, b);
     }
   }
 }
 extern "C" int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
-                                     int rows_per_group, int transpose, void* dst, long ld_dst, void* stream) {
+                                     int rows_per_group, int transpose, void* dst, long ld_dst, int dst_rows_per_batch, int dst_shift, void* stream) {
   ASR_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols, ASR_ERR_ARG, "asr_f32_to_bf16_image: bad argument");
   const int rpb = rows_per_batch > 0 ? rows_per_batch : rows;
   ASR_CHECK(!(scale && rows_per_group <= 0), ASR_ERR_ARG, "asr_f32_to_bf16_image: scale needs rows_per_group > 0");
-  ASR_CHECK(ld_dst >= (transpose ? rows : cols), ASR_ERR_SHAPE, "asr_f32_to_bf16_image: destination rows too short");
+  const int drpb = dst_rows_per_batch > 0 ? dst_rows_per_batch : rpb;
+  ASR_CHECK((dst_rows_per_batch == 0 && dst_shift == 0) || (transpose && dst_shift >= 0 && drpb >= rpb + dst_shift), ASR_ERR_ARG,
+            "asr_f32_to_bf16_image: destination batching is for the transposed image, with rows_per_batch + shift <= dst_rows_per_batch");
+  ASR_CHECK(ld_dst >= (transpose ? (long)asr_cdiv(rows, rpb) * drpb : cols), ASR_ERR_SHAPE, "asr_f32_to_bf16_image: destination rows too short");
   hipStream_t st = (hipStream_t)stream;
   if (transpose) {
     hipLaunchKernelGGL(bf16_image_t_kernel, dim3((unsigned)asr_cdiv(cols, 64), (unsigned)asr_cdiv(rows, 64)), dim3(256), 0, st, src, ld_src, rows, cols, rpb,
-                       batch_stride, scale, rows_per_group, static_cast<bf16_t*>(dst), ld_dst);
+                       batch_stride, scale, rows_per_group, static_cast<bf16_t*>(dst), ld_dst, drpb, dst_shift);
   } else {
     ASR_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && batch_stride % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 &&
                   (!scale || ((uintptr_t)scale & 15) == 0),

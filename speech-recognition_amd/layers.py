@@ -422,11 +422,33 @@ class BiRNN:
         def param_grads():      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
             if buf["rdrop"]:
                 return param_grads_per_gate()
+            shared = rt == "lstm" and T > 1 and ops.bf16_images_pay(H, 4 * H, B * (T - 1)) and ops.bf16_images_pay(self.Din, 4 * H, B * T)
             for d, dd in enumerate(buf["dirs"]):
                 nm = self.names[d]
                 ds3 = dd[dskey]
                 ds2 = ds3.view(B * T, -1)
                 mt = dd["mtab"] if buf["drop"] else None
+                if shared:
+                    # wide layers under mixed precision: dW = x^T ds and dU = h_prev^T ds contract over the same B T rows of ds - ONE
+                    # transposed bf16 image of ds serves both (ops.gemm alone would transpose ds twice: 0.23 ms each at las_large);
+                    # h is written one column off inside every clip (h[b, t -+ 1] beside ds[b, t]), the column without a predecessor
+                    # stays zero (a scratch of its own per direction: nothing else writes it)
+                    dsT = ops.f32_to_bf16_image(ds2, ops.image_scratch("dsT", 4 * H, B * T), transpose=True)
+                    xT = ops.f32_to_bf16_image(x2d, ops.image_scratch("a", self.Din, B * T), transpose=True, scale=mt, rows_per_group=T)
+                    ops.gemm_bf16_nt(xT, dsT, g[nm + "kernel"], accumulate=1)
+                    if pws is None:
+                        ops.colsum(ds2, g[nm + "bias"])
+                    hs = dd["hseq"]
+                    hT = ops.image_scratch("hT_r" if dd["reverse"] else "hT_f", H, B * T)
+                    if dd["reverse"]:
+                        ops.f32_to_bf16_image(hs[:, 1:], hT, transpose=True, dst_rows_per_batch=T, dst_shift=0)
+                    else:
+                        ops.f32_to_bf16_image(hs[:, :T - 1], hT, transpose=True, dst_rows_per_batch=T, dst_shift=1)
+                    ops.gemm_bf16_nt(hT, dsT, g[nm + "recurrent_kernel"], accumulate=1)
+                    if dd["h0"] is not None:
+                        t0 = T - 1 if dd["reverse"] else 0
+                        ops.gemm(dd["h0"], ds3[:, t0], g[nm + "recurrent_kernel"], trans_a=True, accumulate=1)
+                    continue
                 cell_param_grads(rt, H, x2d, None, ds2, g[nm + "kernel"], None, None if pws is not None else g[nm + "bias"], a_scale=mt, a_rpg=T)
                 # recurrent kernel: sum_t h_{prev(t)}^T ds_t with the sequence shifted by one processing step
                 hs = dd["hseq"]

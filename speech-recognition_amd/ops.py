@@ -348,17 +348,30 @@ def _image_scratch(role, rows, cols):
     return buf
 
 
-def f32_to_bf16_image(src, dst, *, transpose=False, scale=None, rows_per_group=0):
+def f32_to_bf16_image(src, dst, *, transpose=False, scale=None, rows_per_group=0, dst_rows_per_batch=0, dst_shift=0):
     """dst (bf16 [rows, >= cols] or, transposed, [cols, >= rows]) = bf16(src * scale[row / rows_per_group]).  src: f32 2-D with unit
-    inner stride, or 3-D [batch, rows, cols] (flattened row-major over (batch, row))."""
+    inner stride, or 3-D [batch, rows, cols] (flattened row-major over (batch, row)).  dst_rows_per_batch / dst_shift (transposed, 3-D
+    source): batch b's rows land at columns b * dst_rows_per_batch + dst_shift + row; the other columns are left alone."""
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.stride(-1) == 1 and dst.stride(-1) == 1
     if src.dim() == 3:
         rows, rpb, bstr = src.shape[0] * src.shape[1], src.shape[1], src.stride(0)
     else:
         rows, rpb, bstr = src.shape[0], 0, 0
     check(lib().asr_f32_to_bf16_image(_p(src), src.stride(-2), rows, src.shape[-1], rpb, bstr, _p(scale) if scale is not None else None,
-                                      int(rows_per_group), int(transpose), C.c_void_p(dst.data_ptr()), dst.stride(0), _stream()))
+                                      int(rows_per_group), int(transpose), C.c_void_p(dst.data_ptr()), dst.stride(0), int(dst_rows_per_batch),
+                                      int(dst_shift), _stream()))
     return dst
+
+
+def bf16_images_pay(M, N, K) -> bool:
+    """Whether ops.gemm would route an [M,K] x [K,N] product through bf16 images (mixed precision, large in every dimension)."""
+    md = _bf16_images["min_dim"]
+    return bool(mixed_precision() and _bf16_images["on"] and M >= md // 2 and N >= md // 2 and K >= md and M * N >= md * md)
+
+
+def image_scratch(role, rows, cols):
+    """A zero-initialised bf16 [rows, cols rounded up to 8] scratch per (role, stream, shape) - see _image_scratch."""
+    return _image_scratch(role, rows, cols)
 
 
 def gemm_bf16_nt(a16, b16, c, *, alpha=1.0, accumulate=0, bias=None, relu=False, c_scale=None, c_rpg=0, split_k=1, K=None):

@@ -113,3 +113,29 @@ def test_small_products_keep_the_f32_operand_kernel():
     ops.gemm(a, b, c, compute=1)
     assert len(ops._bf16_images["scratch"]) == n
     _check(c, _bf(a) @ _bf(b), a, b)
+
+
+def test_shifted_transposed_image_lets_the_recurrent_gradient_share_the_ds_image():
+    """dU = sum_b sum_t h[b, t - 1]^T ds[b, t]: h is written one column off inside every clip (dst_rows_per_batch / dst_shift), the
+    column without a predecessor stays zero, and the product with the FULL transposed ds image equals the shifted-view product."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(11)
+    Bq, T, H, N = 6, 37, 256, 512
+    hs = torch.randn(Bq, T, H, generator=g).cuda()
+    ds = torch.randn(Bq, T, N, generator=g).cuda()
+    K8 = (Bq * T + 7) // 8 * 8
+    dsT = torch.zeros(N, K8, device="cuda", dtype=torch.bfloat16)
+    ops.f32_to_bf16_image(ds.view(Bq * T, N), dsT, transpose=True)
+    for reverse in (False, True):
+        hT = torch.zeros(H, K8, device="cuda", dtype=torch.bfloat16)
+        if reverse:
+            ops.f32_to_bf16_image(hs[:, 1:], hT, transpose=True, dst_rows_per_batch=T, dst_shift=0)
+            want = torch.einsum("bth,btn->hn", _bf(hs[:, 1:]), _bf(ds[:, :T - 1]))
+        else:
+            ops.f32_to_bf16_image(hs[:, :T - 1], hT, transpose=True, dst_rows_per_batch=T, dst_shift=1)
+            want = torch.einsum("bth,btn->hn", _bf(hs[:, :T - 1]), _bf(ds[:, 1:]))
+        img = hT[:, :Bq * T].float().view(H, Bq, T)
+        assert float(img[:, :, T - 1 if reverse else 0].abs().max()) == 0.0
+        gU = torch.zeros(H, N, device="cuda")
+        ops.gemm_bf16_nt(hT, dsT, gU, accumulate=1)
+        _check(gU, want, hs, ds)
