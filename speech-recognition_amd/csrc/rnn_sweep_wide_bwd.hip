@@ -77,13 +77,15 @@ __device__ __forceinline__ int wb_img(int row, int c) { return row * 256 + ((c ^
 
 __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char img[2][64 * 256];     // ds_t as bf16 [row][k = gate * 32 + unit], by step parity
-  __shared__ int abort_flag;
+  // time-outs are raised during a step's gather and acted upon after that step's barrier, by ALL waves or none: one flag per step parity -
+  // a fast wave that gives up in the gather of step p + 1 must not change what a slow wave reads right behind the barrier of step p
+  __shared__ int abort_par[2];
   const WbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int gi = blockIdx.x >> 2, gj = blockIdx.x & 3;            // grid row (unit group), grid column (output block)
   const int B = a.B, T = a.T, H = a.H;
-  if (tid == 0) { abort_flag = 0; swd_arrive(a.err); }
+  if (tid == 0) { abort_par[0] = 0; abort_par[1] = 0; swd_arrive(a.err); }
   swd_setprio(a.prio);
 
   // ---- element-wise role: lane = (row-in-wave rl, piece q, half sp); 4 consecutive units of one batch row ----
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
       wreg[mt][ks] = (u32x4){wb_pack2(u0.x, u0.y), wb_pack2(u0.z, u0.w), wb_pack2(u1.x, u1.y), wb_pack2(u1.z, u1.w)};
     }
 
-  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) abort_flag = 15;   // the whole grid is resident before the first step
+  if (tid == 0 && !swd_wait_all(a.err, a.spin_limit)) abort_par[0] = 15;   // the whole grid is resident before the first step (acted upon behind step 0's barrier)
   __syncthreads();
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
   const long dir_words = (long)blockIdx.z * WB_SLOTS * WB_SLOT_WORDS;
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
     const bool cell = p < T;
     f32x4 dh = {0.f, 0.f, 0.f, 0.f};
-    if (p > 0 && !abort_flag) {
+    volatile int* const abort_now = &abort_par[p & 1];
+    if (p > 0) {
       // ---------------------------------------------------------------------------------------- gather (32 senders, 16 per thread)
       const uint32_t* src0 = a.xbuf + dir_words + (long)(p % WB_SLOTS) * WB_SLOT_WORDS + g_base;      // wave-uniform
       const uint32_t* src = src0 + g_lane;
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
         const uint32_t* pp = src + 15l * 8 * 1024;                  // the last sender of this lane's half
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(pv) : "v"(pp) : "memory");
         if (__all(wb_fresh(pv)) || (a.dbg & 2)) break;
-        if (*(volatile int*)&abort_flag) { ok2 = false; break; }
-        if (sp2 > a.spin_limit) { abort_flag = 1 | (p << 8); ok2 = false; break; }
+        if (*abort_now) { ok2 = false; break; }
+        if (sp2 > a.spin_limit) { *abort_now = 1 | (p << 8); ok2 = false; break; }
         __builtin_amdgcn_s_sleep(4);
       }
       float acc8[8];
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
           acc8[4] += wb_lo(v[s16].z); acc8[5] += wb_hi(v[s16].z); acc8[6] += wb_lo(v[s16].w); acc8[7] += wb_hi(v[s16].w);
         }
         if (__all(ok) || (a.dbg & 2)) break;
-        if (*(volatile int*)&abort_flag) { ok2 = false; break; }
-        if (spins > a.spin_limit) { abort_flag = 2 | (p << 8); ok2 = false; break; }
+        if (*abort_now) { ok2 = false; break; }
+        if (spins > a.spin_limit) { *abort_now = 2 | (p << 8); ok2 = false; break; }
         __builtin_amdgcn_s_sleep(2);
       }
       if (ok2) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
     f32x4 dstate = dh + dirv;
     if (p == 0 && live && d.dh_last) dstate += *reinterpret_cast<const f32x4*>(d.dh_last + (long)row * d.dh_last_ld + j0);
     if (!cell) {
-      if (live && writer && d.dh0 && !abort_flag) *reinterpret_cast<f32x4*>(d.dh0 + (long)row * d.dh0_ld + j0) = dstate;
+      if (live && writer && d.dh0 && !*abort_now) *reinterpret_cast<f32x4*>(d.dh0 + (long)row * d.dh0_ld + j0) = dstate;
       break;
     }
     f32x4 ds[4];
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
     }
     fetch(p + 1, op);                                              // next step's operands: in flight during the product and the next gather
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: the image is complete
-    if (abort_flag) break;
+    if (*abort_now) break;                                          // (written before the barrier only: every wave reads the same value)
     // ------------------------------------------------------------------------------------------ product + publish
     f32x4 acc[2][4];
 #pragma unroll
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
     }
   }
   __syncthreads();
+  const int abort_flag = abort_par[0] | abort_par[1];
   if (live && writer && !abort_flag) *reinterpret_cast<f32x4*>(d.dc + (long)row * H + j0) = dcv;
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

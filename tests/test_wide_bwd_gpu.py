@@ -45,3 +45,48 @@ def test_wide_bwd_sweep_equals_the_staged_step_kernels(B, T, masked, states):
             assert torch.isfinite(got[key]).all(), (d, key)
             err = _rel(got[key], ref[key])
             assert err < 1e-2, f"direction {d} {key}: relative L2 {err:.2e}"
+
+
+def test_wide_bwd_sweep_timeout_is_reported_not_hung():
+    """With the spin limit forced to 0 every gather gives up at its first stale probe: the launch must end (all ten barriers of the
+    abort path are taken by every wave), raise the error word and the caller's flag, leave a diagnosis record - and the next launch with
+    the normal limit must be clean and correct again (the fill kernel re-arms the exchange and the per-launch diagnosis words)."""
+    from speech_recognition_amd import ops
+    from tests.rnn_helpers import HipBiRNN
+    from tests.test_rnn_gpu import make_params
+    B, T, D, H = 33, 6, 32, 1024
+    g = torch.Generator().manual_seed(3)
+    fwd, bwd = make_params("lstm", D, H, g, 0.03)
+    x = torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    dy = torch.randn(B, T, 2 * H, generator=g).cuda() * 0.05
+    ops.set_mixed_precision(True)
+    try:
+        hip = HipBiRNN("lstm", x, None, fwd, bwd, None)
+        hip.forward(persistent=False)
+        gds = [dict(direct=torch.zeros(B, H, device="cuda"), dy_carry=torch.zeros(B, H, device="cuda"), dh0=torch.zeros(B, H, device="cuda"),
+                    dc=torch.zeros(B, H, device="cuda"), ds=torch.zeros_like(dd["saved"])) for dd in hip.dirs]
+        ws = ops.rnn_sweep_wide_bwd_ws(B, H, 2)
+        flag = torch.zeros(1, device="cuda")
+        ops.rnn_sweep_set_spin_limit(0)
+        try:
+            ops.rnn_sweep_wide_bwd(hip.seq, dy, gds, ws, flag)
+            torch.cuda.synchronize()
+        finally:
+            ops.rnn_sweep_set_spin_limit(1 << 20)
+        assert ops.rnn_persist_error(ws) != 0 and float(flag) == 1.0
+        rep = ops.sweep_diagnosis(ws, "rnn_sweep_wide_bwd", clear=True)
+        assert rep and rep["expected"] == 256 and rep["verdict"] in ("absent workgroup", "lost hand-off"), rep
+        for gd in gds:
+            gd["dc"].zero_()
+        ops.rnn_sweep_wide_bwd(hip.seq, dy, gds, ws, None)
+        torch.cuda.synchronize()
+        assert ops.rnn_persist_error(ws) == 0
+        ref = HipBiRNN("lstm", x, None, fwd, bwd, None)
+        ref.forward(persistent=False)
+        want = ref.backward(dy.cpu().double(), [None] * 4)
+        for d, dd in enumerate(hip.dirs):
+            dsr = ref.dirs[d]["saved"]                                  # (the step kernels leave ds over the saved activations)
+            err = float((gds[d]["ds"] - dsr).norm()) / float(dsr.norm())
+            assert err < 1e-2, (d, err)
+    finally:
+        ops.set_mixed_precision(False)
