@@ -235,6 +235,32 @@ def _sweep_entries(trainer, model, buf, layer, rt, B, T2, H, peak):
         fl = 2.0 * B * T2 * H * ng * H * 2
         out.append(_mfma_entry(f"rnn_sweep_bwd_kernel (Bi{rt.upper()} layer {layer}, H={H}, B={B}, {T2} dependent steps in one launch)", fl, t,
                                PEAK_F32_MFMA, bound="latency (reported against mfma)", us_per_dependent_step=round(t * 1e6 / T2, 2)))
+    # the wide layers' sweeps under mixed precision (las_large): bound by the 128 KB every workgroup gathers per dependent step
+    # (256 workgroups x B x H bf16 through the fabric) - reported against the bf16 MFMA peak like the others, with the
+    # exchange bandwidth they reach next to it
+    if "wide_ws" in buf:
+        t = time_kernel(trainer.stream, lambda: ops.rnn_sweep_wide_fwd(buf["seq"], buf["wide_ws"], err), iters=3)
+        fl = 2.0 * B * T2 * H * ng * H * 2
+        out.append(_mfma_entry(f"rnn_sweepw_fwd_kernel (BiLSTM layer, H={H}, B={B}, {T2} dependent steps in one launch, bf16 weights resident)", fl, t,
+                               PEAK_BF16_MFMA, bound="latency / exchange (reported against mfma)", us_per_dependent_step=round(t * 1e6 / T2, 2),
+                               exchange_GBps=round(2 * (H // 8) * 64 * H * 2 * T2 / t / 1e9, 1)))
+    if "wide_bwd_ws" in buf:
+        dirs = buf["dirs"]
+        dy = torch.randn(B, T2, 2 * H, device="cuda") * 1e-3
+        dcs = [torch.zeros(B, H, device="cuda") for _ in range(2)]
+        gds = [dict(dh_last=None, dc=dcs[d], dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"],
+                    ds=dd["ds"]) for d, dd in enumerate(dirs)]
+
+        def wbwd():
+            for dc in dcs:
+                dc.zero_()
+            ops.rnn_sweep_wide_bwd(buf["seq"], dy, gds, buf["wide_bwd_ws"], err)
+
+        t = time_kernel(trainer.stream, wbwd, iters=3)
+        fl = 2.0 * B * T2 * H * ng * H * 2
+        out.append(_mfma_entry(f"rnn_sweepw_bwd_kernel (BiLSTM layer {layer}, H={H}, B={B}, {T2} dependent steps in one launch, 32x4 grid per "
+                               "direction, bf16 partial sums)", fl, t, PEAK_BF16_MFMA, bound="latency / exchange (reported against mfma)",
+                               us_per_dependent_step=round(t * 1e6 / T2, 2), exchange_GBps=round(256 * 64 * H * 2 * T2 / t / 1e9, 1)))
     return out
 
 
