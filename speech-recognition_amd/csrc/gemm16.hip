@@ -16,12 +16,22 @@
 // 31936 x 2048 activation against ~1-3 ms of product saved.  Epilogue = gemm_core.h's (bias, ReLU, row-group scale, +=, atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm_core.h"
 
 typedef unsigned short bf16_t;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 #define G16_BK 64
+
+template <int I, int N, class F>
+__device__ __forceinline__ void g16_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    g16_static_for<I + 1, N>(f);
+  }
+}
 
 __device__ __forceinline__ int g16_off(int row, int ch) { return row * 128 + 16 * (ch ^ (row & 7)); }   // byte offset of chunk ch (8 bf16) of a tile row
 
@@ -163,15 +173,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
       __syncthreads();
     }
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+  // (compile-time indices: with 4 x 2 accumulator tiles the plain unrolled loops were NOT fully unrolled and the whole accumulator array
+  // went to scratch - 576 bytes per lane, 150 TF)
+  g16_static_for<0, TM>([&](auto i) {
+    g16_static_for<0, 16>([&](auto r) {
+      constexpr int ic = decltype(i)::value, rc = decltype(r)::value;
+      const int row = m0 + (wm * TM + ic) * 32 + (rc & 3) + 8 * (rc >> 2) + 4 * lh;
       const long srow2 = ep.map_row(row);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) ep.put(row, srow2, n0 + (wn * TN + j) * 32 + l31, acc[i][j][r]);
-    }
+      g16_static_for<0, TN>([&](auto j) {
+        constexpr int jc = decltype(j)::value;
+        ep.put(row, srow2, n0 + (wn * TN + jc) * 32 + l31, acc[ic][jc][rc]);
+      });
+    });
+  });
 }
 
 struct G16Launch {
@@ -235,6 +249,10 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
     case 5: g16_launch<2, 2, 2, 2, 2, 1>(g); break;
     case 6: g16_launch<4, 2, 2, 2, 1, 1>(g); break;
     case 7: g16_launch<4, 2, 2, 2, 2, 1>(g); break;
+    case 8: g16_launch<2, 4, 4, 2, 2, 1>(g); break;              // 256 x 256, 8 waves of 128 x 64, direct-to-LDS, two buffers (128 KB LDS)
+    case 9: g16_launch<2, 4, 4, 2, 1, 1>(g); break;
+    case 10: g16_launch<2, 2, 4, 2, 2, 1>(g); break;             // 256 x 128, 4 waves of 128 x 64
+    case 11: g16_launch<2, 2, 4, 2, 1, 1>(g); break;
     default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging
   }
   ASR_LAUNCH_CHECK();
