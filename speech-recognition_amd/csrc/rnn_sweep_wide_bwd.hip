@@ -25,9 +25,13 @@
 // column and is gathered by the 32 workgroups of 8 grid ROWS, so a completed gather of step p proves "my senders finished gather
 // p - 1" and, because their senders together are the whole grid, "everybody finished gather p - 2": six slots, the block of step
 // p - 3 is re-armed when step p is published.
-// All 8 waves do every phase (gather, gate math, product, publish): at ~9 us per step the store acknowledgements a wave waits for
-// before its next poll returns are a small part of the step, unlike in the 3 us f32 sweeps, and the 128 KB gather wants all 512
-// lanes' loads in flight.  LSTM only; H = 1024; B <= 64; masks, chained final-state gradients and dh0 / dc as in asr_rnn_seq_bwd.
+// All 8 waves do every phase (gather, gate math, product, publish).  Measured per step at B = 64, T' = 499 (tests/tools/bench_wide_sweep.py):
+// 9.9 us; 6.5 with neither waits nor publishes; publishes + sentinels cost ~3.5 us of visibility latency (16 MB of write-through
+// stores per step chip-wide) that is NOT the in-order acknowledgement wait of the f32 sweeps: with 8 gather waves + 4 product/publish
+// waves (768 threads, 166 VGPRs, the first probe delayed by the product's duration) the step took 10.0 us, so the simpler
+// one-role structure stays.  Also measured: all four gates of ds from column 0 only (+1.9 us: everybody waits for the slowest
+// workgroups), 4-byte sentinels (+0.65 us: partial-line write-through), no probe before the gather (+1.9 us of retry traffic).
+// LSTM only; H = 1024; B <= 64; masks, chained final-state gradients and dh0 / dc as in asr_rnn_seq_bwd.
 #include <stdlib.h>
 
 #include "sweep_common.h"
