@@ -7,6 +7,8 @@
 //   bwd data     dX[ipos][c] = sum_{r,s,o} dY[b,(h-r)/sh,(w-s)/sw,o] W[r,s,c,o]   (NT, both gathered; one
 //                stride-1 correlation per (h % sh, w % sw) class, see DyClassLoader)
 // pos = (b, ho, wo); kc = (r, s, c) with c fastest - exactly the HWIO kernel's row index.
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 struct ConvGeom {
@@ -175,6 +177,8 @@ struct ConvClass {
 template <int VEC>
 struct ConvClassSet { ConvClass<VEC> c[CONV_MAX_CLASSES]; };
 
+// blockIdx.y = K partition (gridDim.y > 1: the partitions of a tile add up atomically into a pre-zeroed dX - few large tiles leave the
+// last round of workgroups mostly empty: deepspeech conv3 has 558 tiles of 363 K steps for 512 resident workgroups)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs) {
   using T = GemmTile<0, 1, BM, BN, WAVES_M, WAVES_N, BK>;
@@ -197,6 +201,14 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs
       al.Cc = kend;      // the loaders zero-fill from kend on, so the last K tile may be partial
       bl.Cc = kend;
     }
+  }
+  if (gridDim.y > 1) {
+    const int chunk = ((kend - kbeg + (int)gridDim.y - 1) / (int)gridDim.y + BK - 1) / BK * BK;
+    kbeg += (int)blockIdx.y * chunk;
+    if (kbeg >= kend) return;                       // (dX is pre-zeroed: nothing to add)
+    kend = min(kend, kbeg + chunk);
+    al.Cc = kend;
+    bl.Cc = kend;
   }
   T::template run<0>(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
@@ -238,10 +250,21 @@ extern "C" int asr_conv2d_fwd(const asr_conv_desc* d, const float* x, const floa
   const AsrDiv dWo = asr_make_div(g.Wo), dHo = asr_make_div(g.Ho), dRow = asr_make_div(g.kw * g.C);
   Im2colLoader<1> av{x, g, M, K, dWo, dHo, dRow};
   Im2colLoader<0> as{x, g, M, K, dWo, dHo, dRow};
-  if (N <= 32) {
+  static const int fwd_small = getenv("ASR_CONV_FWD_SMALL") ? atoi(getenv("ASR_CONV_FWD_SMALL")) : 1;
+  static const int narrow_bm = getenv("ASR_CONV_FWD_BM") ? atoi(getenv("ASR_CONV_FWD_BM")) : 128;
+  if (N <= 32 && narrow_bm == 128) {
+    const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 32);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else hipLaunchKernelGGL((conv_fwd_kernel<128, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
+  } else if (N <= 32) {
     const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
     if (vec) hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
     else hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
+  } else if (vec && fwd_small) {
+    // 64 x 64 tiles: deepspeech conv3 (M = 40320, N = 96) makes 630 workgroups of 128 x 64 - a full round and a 23 % one at two per CU;
+    // 1260 smaller ones balance better (922 -> 840 us); one 128-wide column tile (im2col gathered once) measured 1209 us
+    const int tm = asr_cdiv(M, 64), tn = asr_cdiv(N, 64);
+    hipLaunchKernelGGL((conv_fwd_kernel<64, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
   } else {
     const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
     if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
@@ -267,7 +290,11 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   Im2colLoader<0> as{x, g, K, M, dWo, dHo, dRow};
   const bool narrow = N <= 32;
   const bool tiny = M <= 32;     // a 3x3x3 first-layer filter: 27 rows - a 32-row tile wastes far fewer MFMAs than a 256-row one
-  const int tm = asr_cdiv(M, tiny ? 32 : (narrow ? 256 : 64)), tn = asr_cdiv(N, tiny ? 128 : (narrow ? 32 : 64));
+  static const int wide_env = getenv("ASR_CONV_DW_WIDE") ? atoi(getenv("ASR_CONV_DW_WIDE")) : 1;
+  const bool wide = !tiny && !narrow && N > 64 && N <= 128 && wide_env != 0;   // 96 output channels: ONE 128-wide column tile gathers im2col once
+  const int wbm = wide_env == 2 ? 64 : 128;
+  static const int dw_bm = getenv("ASR_CONV_DW_BM") ? atoi(getenv("ASR_CONV_DW_BM")) : 128;
+  const int tm = asr_cdiv(M, tiny ? 32 : (narrow ? dw_bm : (wide ? wbm : 64))), tn = asr_cdiv(N, tiny ? 128 : (narrow ? 32 : (wide ? 128 : 64)));
   int splits = 1024 / (tm * tn);
   if (splits < 1) splits = 1;
   const int bk = 32;                         // K partitions are whole K tiles of the kernel used
@@ -278,8 +305,12 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)splits);
   if (tiny && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else if (tiny) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (narrow && vec && dw_bm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (narrow && dw_bm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
   else if (narrow && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else if (narrow) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (wide && vec && wbm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (wide && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 128, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else if (vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
   else hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
   ASR_LAUNCH_CHECK();
@@ -295,15 +326,42 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
   hipStream_t st = (hipStream_t)stream;
   const int o_vec = (g.O % 4 == 0) && al16(dy) && al16(w);
   const bool narrow = N <= 32;
-  const int BMh = narrow ? 256 : 128, BNh = narrow ? 32 : 64;
+  static const int dx_bm = getenv("ASR_CONV_DX_BM") ? atoi(getenv("ASR_CONV_DX_BM")) : 128;
+  const int BMh = narrow ? dx_bm : 128, BNh = narrow ? 32 : 64;
   // classes in chunks of CONV_MAX_CLASSES per launch (sh * sw <= 4 for every shipped model: one launch)
   ConvClassSet<1> sv{};
   ConvClassSet<0> ss{};
   int n = 0, max_tiles = 0;
+  // K partitions: when all classes together make fewer than ~8 workgroups per CU and K is long, split K (atomic accumulation into a
+  // zeroed dX).  deepspeech conv3: 558 tiles x 363 K steps -> 4 partitions (1447 -> see DESIGN.md); conv2: 1598 -> 2
+  int splits = 1;
+  {
+    static const int split_env = getenv("ASR_CONV_DX_SPLIT") ? atoi(getenv("ASR_CONV_DX_SPLIT")) : -1;
+    long tiles_all = 0;
+    int kmax = 0;
+    for (int ph = 0; ph < g.sh; ++ph)
+      for (int pw = 0; pw < g.sw; ++pw) {
+        const int Hq = (g.H - ph + g.sh - 1) / g.sh, Wq = (g.W - pw + g.sw - 1) / g.sw;
+        if (Hq <= 0 || Wq <= 0) continue;
+        const int nR = ph < g.kh ? (g.kh - ph + g.sh - 1) / g.sh : 0, nS = pw < g.kw ? (g.kw - pw + g.sw - 1) / g.sw : 0;
+        tiles_all += (long)asr_cdiv((long)g.B * Hq * Wq, BMh) * asr_cdiv(N, BNh);
+        kmax = nR * nS * g.O > kmax ? nR * nS * g.O : kmax;
+      }
+    if (kmax >= 2048 && tiles_all > 0 && tiles_all < 2048) splits = (int)((2048 + tiles_all - 1) / tiles_all);
+    if (splits > 4) splits = 4;
+    if (split_env >= 1) splits = split_env;
+    if ((long)g.sh * g.sw > CONV_MAX_CLASSES) splits = 1;   // (several launches over one dX: keep the plain stores)
+  }
+  if (splits > 1 && asr_zero_async(dx, sizeof(float) * (size_t)g.B * g.H * g.W * g.C, st) != hipSuccess) {
+    asr_set_error("asr_conv2d_bwd_data: zeroing dX failed");
+    return ASR_ERR_HIP;
+  }
   auto flush = [&]() {
     if (n == 0) return;
-    dim3 grid((unsigned)max_tiles, 1, (unsigned)n);
-    if (narrow && o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
+    dim3 grid((unsigned)max_tiles, (unsigned)splits, (unsigned)n);
+    if (narrow && o_vec && BMh == 128) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
+    else if (narrow && BMh == 128) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, ss);
+    else if (narrow && o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
     else if (narrow) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, ss);
     else if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, sv);
     else hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, ss);
@@ -319,7 +377,7 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
       const AsrDiv dHq = asr_make_div(Hq), dWq = asr_make_div(Wq), dO = asr_make_div(g.O), dnR = asr_make_div(nRd);
       const int k_per_j = (K > 0 && (nR * g.O) % 4 == 0) ? nR * g.O : 0;   // K ranges start on a float4 boundary
       const int tm = asr_cdiv(M, BMh), tn = asr_cdiv(N, BNh);
-      GemmEpilogue ep{dx, (long)N, M, N, 1.f, nullptr, nullptr, 1, 0, 0, nullptr, 0u, 0.f, 1, Hq, Wq, g.sh, g.sw, ph, pw, g.H, g.W};
+      GemmEpilogue ep{dx, (long)N, M, N, 1.f, nullptr, nullptr, 1, splits > 1 ? 2 : 0, 0, nullptr, 0u, 0.f, 1, Hq, Wq, g.sh, g.sw, ph, pw, g.H, g.W};
       sv.c[n] = ConvClass<1>{DyClassLoader<1>{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR}, WtClassLoader<1>{w, g, ph, pw, nRd, N, K, dO, dnR}, ep,
                              K, tm, tm * tn, k_per_j};
       ss.c[n] = ConvClass<0>{DyClassLoader<0>{dy, g, Hq, Wq, nRd, M, K, dHq, dWq, dO, dnR}, WtClassLoader<0>{w, g, ph, pw, nRd, N, K, dO, dnR}, ep,
