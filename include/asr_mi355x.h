@@ -152,6 +152,7 @@ int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream)
  * bf16(src[r][c] * scale[r / rows_per_group][c]); source row r = batch r / rows_per_batch (stride batch_stride) x row r % rows_per_batch
  * (rows_per_batch 0 = one batch), so that the shifted [B, T-1, H] views of the recurrent-kernel gradient flatten into one product. */
 int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream);
+int asr_debug_sweep_trace(unsigned long long* out, int n);   /* timing aid: stage stamps of one BPTT-sweep workgroup (ASR_SWEEP_DBG bit 128), 8 per step */
 int asr_gemm_bf16_config(int cfg);   /* tile configuration of asr_gemm_bf16_nt (tuning and tests; -1 = query); returns the previous one */
 int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
                           int rows_per_group, int transpose, void* dst, long ld_dst, int dst_rows_per_batch, int dst_shift, void* stream);

@@ -149,6 +149,7 @@ SIGNATURES = {
     "asr_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_gemm_bf16_config": (C.c_int, [C.c_int]),
+    "asr_debug_sweep_trace": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "asr_f32_to_bf16_image": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, c_long, _P, C.c_int, C.c_int, _P, c_long, C.c_int, C.c_int, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),

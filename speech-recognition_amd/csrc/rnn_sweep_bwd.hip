@@ -53,6 +53,12 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Stage timeline of ONE workgroup (block 0 of group 0; ASR_SWEEP_DBG bit 128; read back with asr_debug_sweep_trace): per step eight
+// s_memrealtime stamps (10 ns ticks) - 0 gather entered, 1 gather complete, 2 gate gradients done, 3 partial block in LDS,
+// 4 publish wave saw all four partial blocks, 5 publish + re-arm issued.  Timing aid only.
+#define SB_TRACE_STEPS 512
+__device__ unsigned long long sb_trace[SB_TRACE_STEPS * 8];
+
 struct SbDir {
   const float* U; long ldu;
   const float* coef;            // [B,T,H,CW]: the element-wise backward as coefficients, written by the forward sweep (asr_rnn_seq.coef)
@@ -232,6 +238,8 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       float sa[NT];
 #pragma unroll
       for (int r = 0; r < NT; ++r) sa[r] = 0.f;
+      const bool tracing = (a.dbg & 128) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wv == 0 && p < SB_TRACE_STEPS;
+      if (tracing && lane == 0) sb_trace[p * 8 + 0] = __builtin_amdgcn_s_memrealtime();
       if (p > 0) {
         const float* src = xb + (long)(p % SB_SLOTS) * slot_floats + row_off + pos_off;
         const bool u0 = pt < G, u1 = pt + LP < G, u2 = pt + 2 * LP < G, u3 = pt + 3 * LP < G;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           sa[r] = c == 0 ? acc.x : (c == 1 ? acc.y : (c == 2 ? acc.z : acc.w));
         }
       }
+      if (tracing && lane == 0) sb_trace[p * 8 + 1] = __builtin_amdgcn_s_memrealtime();
       // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
       f32x4 k0[NT], k1[NT];
       float dyv[NT], addAv[NT];
@@ -338,6 +347,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
       }
       if (!cell) break;
+      if (tracing && lane == 0) sb_trace[p * 8 + 2] = __builtin_amdgcn_s_memrealtime();
       // the wave's ds image in its own LDS rows, gate slots in the order the recurrent kernel's column blocks take them
       // (GRU: z, r, r (.) d(a_hh); the input-side slot 2 does not multiply U), then read back as MFMA A operands: lane (li, lq) =
       // (row, gate slot) of unit ks - the same wave wrote it, its LDS accesses execute in order
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       for (int t2 = 0; t2 < NT; ++t2) *reinterpret_cast<f32x4*>(&part[p & 1][wv][t2][lane * 4]) = acc[t2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) *(volatile int*)&g_done[wv] = p + 1;
+      if (tracing && lane == 0) sb_trace[p * 8 + 3] = __builtin_amdgcn_s_memrealtime();
       // off the critical path from here: the operands of the next step.  (ds goes to memory from the publish waves: in this wave the
       // stores would sit in front of the next gather's polls in the in-order memory counter - measured +0.76 us per step)
       fetch(p + 1, nxt);
@@ -392,12 +403,27 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         __builtin_amdgcn_s_sleep(1);
       }
       if (!ok) break;
+      const bool tracing = (a.dbg & 128) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wv == 4 && p < SB_TRACE_STEPS;
+      if (tracing && lane == 0) sb_trace[p * 8 + 4] = __builtin_amdgcn_s_memrealtime();
       f32x4 acc = *reinterpret_cast<const f32x4*>(&part[p & 1][0][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][1][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][2][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][3][nt_][lane * 4]);
-      // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+      // Retire this wave's stores up to and including those of step p - 2, then publish and re-arm.  What the protocol needs: the
+      // sentinel stored at step q (over the block of step q - 3) must be visible before a reader polls that slot again, for its gather
+      // of step q + 4.  The reader gets there only after consuming this publisher's block of step q + 2, and that block is issued
+      // behind THIS wait of step q + 2, which covers the stores of step q.  (The same slot's next data store, at step q + 3, is
+      // ordered behind the sentinel the same way.)  Waiting for ALL stores - vmcnt(0), rounds 1-3 - also waited for the
+      // acknowledgements of step p - 1's write-through stores, ~3 us old: 0.6 us of every step's critical path (tests/tools/sweep_trace.py).
+      // In steady state a lane issues 2 stores per step (publish, sentinel), the square's column 0 NS more (ds): allow that many in flight.
+      if (a.dbg & 64) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
+      } else if (writer) {
+        if constexpr (NS == 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(2)" ::: "memory");
+      }
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 2) % SB_SLOTS) * slot_floats + my_blk;   // the block of step p - 3
       if (local) {                                                   // the group sits on one XCD: plain stores keep the lines in its L2
@@ -407,6 +433,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         if (!(a.dbg & 4)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsrc, (int)(dst * 4), 0, 16);   // aux 16 = sc1
         if (p >= 3 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
       }
+      if (tracing && lane == 0) sb_trace[p * 8 + 5] = __builtin_amdgcn_s_memrealtime();
       if (writer) {
         // this step's ds, [B, T, NS * H] row-major: 16-byte pieces (row, gate, 4 units), consecutive lanes on consecutive pieces of a
         // (row, gate) run; the next step's `s_waitcnt vmcnt(0)` retires them a whole exchange round later
@@ -460,6 +487,11 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     if (a.err_flag) __hip_atomic_store(reinterpret_cast<unsigned*>(a.err_flag), 0x3F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) swd_depart(a.err);
+}
+
+extern "C" int asr_debug_sweep_trace(unsigned long long* out, int n) {
+  if (!out || n <= 0 || n > SB_TRACE_STEPS * 8) return ASR_ERR_ARG;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sb_trace), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? ASR_OK : ASR_ERR_HIP;
 }
 
 // geometry: tiles per unit group (1 or 2) and the side G of the workgroup square of one (direction, batch tile) group
