@@ -409,14 +409,13 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][1][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][2][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][3][nt_][lane * 4]);
-      // Retire this wave's stores up to and including those of step p - 2, then publish and re-arm.  What the protocol needs: the
-      // sentinel stored at step q (over the block of step q - 3) must be visible before a reader polls that slot again, for its gather
-      // of step q + 4.  The reader gets there only after consuming this publisher's block of step q + 2, and that block is issued
-      // behind THIS wait of step q + 2, which covers the stores of step q.  (The same slot's next data store, at step q + 3, is
-      // ordered behind the sentinel the same way.)  Waiting for ALL stores - vmcnt(0), rounds 1-3 - also waited for the
-      // acknowledgements of step p - 1's write-through stores, ~3 us old: 0.6 us of every step's critical path (tests/tools/sweep_trace.py).
-      // In steady state a lane issues 2 stores per step (publish, sentinel), the square's column 0 NS more (ds): allow that many in flight.
-      if (a.dbg & 64) {
+      // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm.
+      // (A COUNTED wait would do - vmcnt(2), column 0: vmcnt(2 + NS), i.e. only the stores up to step p - 2 retired: the sentinel of
+      // step q must be visible before a reader polls that slot for its gather of step q + 4, which it reaches only after consuming
+      // this publisher's block of step q + 2, issued behind the wait of step q + 2.  It shortens this wave's part of the step from
+      // 0.6 to 0.24 us (tests/tools/sweep_trace.py) but not the step - the gather wave's own loop is as long: 3.27 -> 3.29 us
+      // alone, 785 vs 792 us per launch inside the training step.  ASR_SWEEP_DBG bit 64 keeps it for experiments.)
+      if (!(a.dbg & 64)) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       } else if (writer) {
         if constexpr (NS == 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(6)" ::: "memory");
