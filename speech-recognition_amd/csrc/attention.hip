@@ -17,6 +17,8 @@
 // column chunk) that recomputes the row's scores itself (2, 4 or 8 chunks: las_small 16.99 -> 17.12-17.14 ms per step):
 // a single CU streaming its 320-510 KB through three dependent phases takes longer than the two wide launches plus
 // the 1.7 us boundary between them.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define ATT_RPW 4   // rows per wave in the dot-product kernels
@@ -264,6 +266,110 @@ __global__ __launch_bounds__(256) void attn_bwd_dh16_kernel(const float* p, cons
   }
 }
 
+// Wide rows (the las_large decoder: D = 2048, Hd = 1024): one column per lane makes 2-byte loads - 128 bytes per wave instruction, 2.6 TB/s
+// on the 130 MB stream of enc.  Here a lane owns VW consecutive columns (16- or 8-byte loads: 1 KB / 512 B per wave instruction), a
+// workgroup 64 VW columns of one batch row, its four waves split the rows of the clip.
+template <int VW>
+__device__ __forceinline__ void weighted_colsum16v(const float* wgt, const unsigned short* Xb, int T, int D, int c0, int w, float (&acc)[VW]) {
+  typedef unsigned int uvec __attribute__((ext_vector_type(VW / 2)));
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  for (int t0 = w; t0 < T; t0 += 4 * ATT_UNR) {
+    uvec x[ATT_UNR];
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) {
+      const int t = t0 + 4 * i;
+      if (t < T) x[i] = *reinterpret_cast<const uvec*>(Xb + (long)t * D + c0);
+      else x[i] = uvec(0u);
+    }
+#pragma unroll
+    for (int i = 0; i < ATT_UNR; ++i) {
+      const int t = t0 + 4 * i;
+      const float wt = t < T ? wgt[t] : 0.f;
+#pragma unroll
+      for (int j = 0; j < VW / 2; ++j) {
+        acc[2 * j] = fmaf(wt, __uint_as_float(x[i][j] << 16), acc[2 * j]);
+        acc[2 * j + 1] = fmaf(wt, __uint_as_float(x[i][j] & 0xffff0000u), acc[2 * j + 1]);
+      }
+    }
+  }
+}
+template <int VW>
+static size_t attn_smem_v(int T) { return sizeof(float) * ((size_t)T + 4 * 64 * VW + 16); }
+
+template <int VW>
+__global__ __launch_bounds__(256) void attn_softmax_ctx16v_kernel(const float* e, const unsigned short* enc, int T, int D, float* p_out, float* ctx,
+                                                                  long ldctx) {
+  extern __shared__ float sm[];
+  float* p = sm;
+  float* part = sm + T;
+  float* red = part + 4 * 64 * VW;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, c0 = (blockIdx.x * 64 + lane) * VW;
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += 256) { const float v = e[(long)b * T + t]; p[t] = v; mx = fmaxf(mx, v); }
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { const float v = expf(p[t] - mx); p[t] = v; s += v; }
+  s = block_sum(s, red);
+  const float inv = 1.f / s;
+  __syncthreads();
+  if (blockIdx.x == 0 && p_out)
+    for (int t = threadIdx.x; t < T; t += 256) p_out[(long)b * T + t] = p[t] * inv;
+  float acc[VW];
+  weighted_colsum16v<VW>(p, enc + (long)b * T * D, T, D, c0, w, acc);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) part[(w * 64 + lane) * VW + j] = acc[j];
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int o = lane * VW + j;
+      ctx[(long)b * ldctx + c0 + j] = (part[o] + part[64 * VW + o] + part[128 * VW + o] + part[192 * VW + o]) * inv;
+    }
+  }
+}
+
+template <int VW>
+__global__ __launch_bounds__(256) void attn_bwd_dh16v_kernel(const float* p, const float* dp, const unsigned short* Kq, int T, int Hd, float* ds_out,
+                                                             float* dh, long lddh, int accumulate) {
+  extern __shared__ float sm[];
+  float* ds = sm;
+  float* part = sm + T;
+  float* red = part + 4 * 64 * VW;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, c0 = (blockIdx.x * 64 + lane) * VW;
+  float dot = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) dot = fmaf(p[(long)b * T + t], dp[(long)b * T + t], dot);
+  dot = block_sum(dot, red);
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float v = p[(long)b * T + t] * (dp[(long)b * T + t] - dot);
+    ds[t] = v;
+    if (blockIdx.x == 0 && ds_out) ds_out[(long)b * T + t] = v;
+  }
+  __syncthreads();
+  float acc[VW];
+  weighted_colsum16v<VW>(ds, Kq + (long)b * T * Hd, T, Hd, c0, w, acc);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) part[(w * 64 + lane) * VW + j] = acc[j];
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int o = lane * VW + j;
+      const float v = part[o] + part[64 * VW + o] + part[128 * VW + o] + part[192 * VW + o];
+      float* op = dh + (long)b * lddh + c0 + j;
+      *op = accumulate ? *op + v : v;
+    }
+  }
+}
+// columns per lane for a row of `cols` bf16: the widest loads that still make ~a workgroup per compute unit (0 = the one-column kernels)
+static int attn_vw(int cols, int B) {
+  static const int on = getenv("ASR_ATTN_VEC") ? atoi(getenv("ASR_ATTN_VEC")) : 1;
+  if (!on) return 0;
+  if (cols % 512 == 0 && (long)(cols / 512) * B >= 192) return 8;
+  if (cols % 256 == 0 && (long)(cols / 256) * B >= 192) return 4;
+  return 0;
+}
+
 extern "C" int asr_attn_step_fwd_bf16(const float* h, long ldh, const void* Kq16, const float* s0, const uint8_t* mask, const void* enc16, int B,
                                       int T, int Hd, int D, float* e, float* p, float* ctx, long ldctx, void* stream) {
   ASR_CHECK(h && Kq16 && mask && enc16 && e && p && ctx, ASR_ERR_ARG, "asr_attn_step_fwd_bf16: null argument");
@@ -273,8 +379,16 @@ extern "C" int asr_attn_step_fwd_bf16(const float* h, long ldh, const void* Kq16
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_rowdot16_kernel, dim3((unsigned)asr_cdiv(T, 4 * ATT_RPW), (unsigned)B), dim3(256), 0, st, h, ldh,
                      static_cast<const unsigned short*>(Kq16), s0, mask, T, Hd, e);
-  hipLaunchKernelGGL(attn_softmax_ctx16_kernel, dim3((unsigned)asr_cdiv(D, 64), (unsigned)B), dim3(256), attn_smem(T), st, (const float*)e,
-                     static_cast<const unsigned short*>(enc16), T, D, p, ctx, ldctx);
+  const int vw = ((uintptr_t)enc16 & 15) == 0 ? attn_vw(D, B) : 0;
+  if (vw == 8)
+    hipLaunchKernelGGL(attn_softmax_ctx16v_kernel<8>, dim3((unsigned)(D / 512), (unsigned)B), dim3(256), attn_smem_v<8>(T), st, (const float*)e,
+                       static_cast<const unsigned short*>(enc16), T, D, p, ctx, ldctx);
+  else if (vw == 4)
+    hipLaunchKernelGGL(attn_softmax_ctx16v_kernel<4>, dim3((unsigned)(D / 256), (unsigned)B), dim3(256), attn_smem_v<4>(T), st, (const float*)e,
+                       static_cast<const unsigned short*>(enc16), T, D, p, ctx, ldctx);
+  else
+    hipLaunchKernelGGL(attn_softmax_ctx16_kernel, dim3((unsigned)asr_cdiv(D, 64), (unsigned)B), dim3(256), attn_smem(T), st, (const float*)e,
+                       static_cast<const unsigned short*>(enc16), T, D, p, ctx, ldctx);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -288,8 +402,16 @@ extern "C" int asr_attn_step_bwd_bf16(const float* dctx, long lddctx, const floa
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_rowdot16_kernel, dim3((unsigned)asr_cdiv(T, 4 * ATT_RPW), (unsigned)B), dim3(256), 0, st, dctx, lddctx,
                      static_cast<const unsigned short*>(enc16), (const float*)nullptr, (const uint8_t*)nullptr, T, D, dp);
-  hipLaunchKernelGGL(attn_bwd_dh16_kernel, dim3((unsigned)asr_cdiv(Hd, 64), (unsigned)B), dim3(256), attn_smem(T), st, p, (const float*)dp,
-                     static_cast<const unsigned short*>(Kq16), T, Hd, ds, dh, lddh, accumulate);
+  const int vw = ((uintptr_t)Kq16 & 15) == 0 ? attn_vw(Hd, B) : 0;
+  if (vw == 8)
+    hipLaunchKernelGGL(attn_bwd_dh16v_kernel<8>, dim3((unsigned)(Hd / 512), (unsigned)B), dim3(256), attn_smem_v<8>(T), st, p, (const float*)dp,
+                       static_cast<const unsigned short*>(Kq16), T, Hd, ds, dh, lddh, accumulate);
+  else if (vw == 4)
+    hipLaunchKernelGGL(attn_bwd_dh16v_kernel<4>, dim3((unsigned)(Hd / 256), (unsigned)B), dim3(256), attn_smem_v<4>(T), st, p, (const float*)dp,
+                       static_cast<const unsigned short*>(Kq16), T, Hd, ds, dh, lddh, accumulate);
+  else
+    hipLaunchKernelGGL(attn_bwd_dh16_kernel, dim3((unsigned)asr_cdiv(Hd, 64), (unsigned)B), dim3(256), attn_smem(T), st, p, (const float*)dp,
+                       static_cast<const unsigned short*>(Kq16), T, Hd, ds, dh, lddh, accumulate);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

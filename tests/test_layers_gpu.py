@@ -192,7 +192,7 @@ def test_attention_step_forward_backward(B, T, Hd, D):
     assert_close(dh - 1.0, gh, 1e-4, "dh through the scores")
 
 
-@pytest.mark.parametrize("B,T,Hd,D", [(5, 13, 128, 128), (7, 61, 1024, 2048), (3, 111, 16, 32)])
+@pytest.mark.parametrize("B,T,Hd,D", [(5, 13, 128, 128), (7, 61, 1024, 2048), (3, 111, 16, 32), (64, 37, 1024, 2048), (48, 29, 512, 1024)])
 def test_attention_step_with_bf16_images(B, T, Hd, D):
     """--mixed-precision: Kq and enc are streamed from bf16 images; products and sums in f32.  The results equal the
     float64 attention on the ROUNDED Kq / enc to f32 accuracy."""
