@@ -8,9 +8,13 @@
 // ("NT": A rows and B rows both run along K), so that a lane's 16-byte LDS read IS its MFMA operand (8 consecutive k):
 //   v_mfma_f32_32x32x16_bf16: A lane l = (row l & 31, k 8 (l >> 5) .. + 7), B likewise with the column; C col = l & 31,
 //   row = (r & 3) + 8 (r >> 2) + 4 (l >> 5).
-// Tile 128 x 128 x 64, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles; global -> registers -> LDS staging with the next
-// tile's loads in flight during the MFMAs (as gemm_core.h); LDS rows of 64 bf16 = 128 B, the 16-byte chunk index XORed with
-// (row & 7) so that the 32 rows a half-wave reads at one k offset fall on different banks.
+// Default schedule (configuration 12, K a multiple of 64 with at least three K tiles): tile 256 x 128 x 64, 8 waves as 4 x 2, each
+// 64 x 64 = 2 x 2 MFMA tiles; the tiles go global -> LDS DIRECTLY (global_load_lds_dwordx4, the swizzle applied to the per-lane
+// source chunk) into THREE buffers, two tiles ahead, with a counted s_waitcnt and a raw s_barrier so that the loads stay in
+// flight across the barrier (one barrier per K tile): 913 TF on the weight-gradient shape against 789 for the fallback.
+// Fallback (any K multiple of 8; configuration 0): tile 128 x 128 x 64, 4 waves as 2 x 2, global -> registers -> LDS staging with
+// the next tile's loads in flight during the MFMAs (as gemm_core.h).  LDS rows of 64 bf16 = 128 B, the 16-byte chunk index XORed
+// with (row & 7) so that the 32 rows a half-wave reads at one k offset fall on different banks.
 // The images are produced by memory-bound conversion passes (f32 -> bf16, optionally times the Keras input-dropout row-group
 // table, optionally TRANSPOSED: the weight-gradient products contract over the rows of both activations): ~0.1 ms per
 // 31936 x 2048 activation against ~1-3 ms of product saved.  Epilogue = gemm_core.h's (bias, ReLU, row-group scale, +=, atomics).
@@ -135,7 +139,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
         __builtin_amdgcn_global_load_lds(B + (long)nb * ldb + k0 + 8 * c8, (lds_ptr_t)(Bs + g * 1024), 16, 0, 0);
       }
     };
-    if constexpr (NBUF == 2) {
+    if constexpr (NBUF == 3) {
+      // Three buffers, loads TWO tiles ahead and in flight ACROSS the barrier: a counted wait (the youngest tile's loads may stay
+      // outstanding: a wave's loads return in order) and a raw s_barrier - __syncthreads() would drain the LDS-DMA queue first.
+      // Tile kt + 2 goes into the buffer compute(kt - 1) read: behind the barrier every wave is done with it.
+      constexpr int LPT = BM / 8 / NW + BN / 8 / NW;            // direct-to-LDS loads per tile and wave
+      stage(kbeg, 0);
+      if (nk > 1) stage(kbeg + G16_BK, 1);
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(kbeg + (kt + 2) * G16_BK, (kt + 2) % 3);
+        compute(kt % 3);
+      }
+    } else if constexpr (NBUF == 2) {
       stage(kbeg, 0);
       for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -208,7 +227,7 @@ static void g16_launch(const G16Launch& g) {
 }
 static int g16_cfg = -1;
 static int g16_config() {
-  if (g16_cfg < 0) { const char* e = getenv("ASR_G16_CFG"); g16_cfg = e ? atoi(e) : 0; }
+  if (g16_cfg < 0) { const char* e = getenv("ASR_G16_CFG"); g16_cfg = e ? atoi(e) : 12; }
   return g16_cfg;
 }
 extern "C" int asr_gemm_bf16_config(int cfg) {                   // tuning / tests: select the tile configuration (-1: leave), returns the previous one
@@ -241,6 +260,7 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
   const bool whole = d->K % G16_BK == 0;                        // (k_chunk is a multiple of 64 by construction)
   int cfg = g16_config();
   if (!whole && cfg >= 4) cfg = 0;
+  if (cfg >= 12 && cfg <= 14 && asr_cdiv(d->K, sk) < 3 * G16_BK) cfg = 0;   // (the three-buffer pipeline wants at least three K tiles)
   switch (cfg) {
     case 1: g16_launch<2, 2, 2, 2, 2, 0>(g); break;
     case 2: g16_launch<4, 2, 2, 2, 2, 0>(g); break;              // 256 x 128, 8 waves
@@ -252,8 +272,11 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
     case 8: g16_launch<2, 4, 4, 2, 2, 1>(g); break;              // 256 x 256, 8 waves of 128 x 64, direct-to-LDS, two buffers (128 KB LDS)
     case 9: g16_launch<2, 4, 4, 2, 1, 1>(g); break;
     case 10: g16_launch<2, 2, 4, 2, 2, 1>(g); break;             // 256 x 128, 4 waves of 128 x 64
+    case 12: g16_launch<4, 2, 2, 2, 3, 1>(g); break;             // 256 x 128, 8 waves, THREE buffers, loads in flight across the barrier
+    case 13: g16_launch<2, 2, 2, 2, 3, 1>(g); break;             // 128 x 128, 4 waves, three buffers
+    case 14: g16_launch<2, 2, 4, 2, 3, 1>(g); break;             // 256 x 128, 4 waves of 128 x 64, three buffers
     case 11: g16_launch<2, 2, 4, 2, 1, 1>(g); break;
-    default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging
+    default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging (any K; the fallback of 12)
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
