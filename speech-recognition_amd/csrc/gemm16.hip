@@ -227,7 +227,7 @@ static void g16_launch(const G16Launch& g) {
 }
 static int g16_cfg = -1;
 static int g16_config() {
-  if (g16_cfg < 0) { const char* e = getenv("ASR_G16_CFG"); g16_cfg = e ? atoi(e) : 12; }
+  if (g16_cfg < 0) { const char* e = getenv("ASR_G16_CFG"); g16_cfg = e ? atoi(e) : 100; }   // 100 = by shape
   return g16_cfg;
 }
 extern "C" int asr_gemm_bf16_config(int cfg) {                   // tuning / tests: select the tile configuration (-1: leave), returns the previous one
@@ -259,6 +259,9 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
   const G16Launch g{static_cast<const bf16_t*>(A16), static_cast<const bf16_t*>(B16), ep, d, sk, (hipStream_t)stream};
   const bool whole = d->K % G16_BK == 0;                        // (k_chunk is a multiple of 64 by construction)
   int cfg = g16_config();
+  // by shape: the three-buffer pipeline pays with many K tiles per workgroup (weight / input gradients, K >= 2048); products with a
+  // short K and a large C ([8128 x 1024] x [1024 x 16000]: 459 against 540 us) are bound by writing C and want more, smaller workgroups
+  if (cfg == 100) cfg = (d->K / sk >= 2048) ? 12 : 0;
   if (!whole && cfg >= 4) cfg = 0;
   if (cfg >= 12 && cfg <= 14 && asr_cdiv(d->K, sk) < 3 * G16_BK) cfg = 0;   // (the three-buffer pipeline wants at least three K tiles)
   switch (cfg) {
