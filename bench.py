@@ -462,10 +462,11 @@ def main():
     trainer, model, dt, dev_ms, (loss, correct, kept), failed = measure()
     retried = 0
     if failed and _layers.PERSISTENT_RNN:
-        # never report a step whose results are invalid.  A single time-out is treated as a transient (one was seen in ~50 runs of
-        # the deepspeech workload on a shared host and never reproduced): measure once more as configured; a second
-        # failure redoes the whole measurement on the per-step recurrent kernels (every rank takes these branches together - the
-        # flag was all-reduced)
+        # never report a step whose results are invalid.  The one time-out ever recorded (round 2) was the BPTT sweep's re-arm lag,
+        # fixed in round 3; the safety net stays, and it is never silent: config.sweep_errors carries the diagnosis
+        # record of every attempt that failed, config.remeasured how far down this ladder the run went.  Measure once more as
+        # configured; a second failure redoes the whole measurement on the per-step recurrent kernels (every rank takes these
+        # branches together - the flag was all-reduced)
         retried = 1
         del trainer, model
         torch.cuda.empty_cache()
