@@ -1,4 +1,4 @@
-// Shared by the five one-launch sweeps (rnn_sweep.hip, rnn_sweep_bwd.hip, rnn_sweep_wide.hip, decoder_sweep.hip,
+// Shared by the six one-launch sweeps (rnn_sweep.hip, rnn_sweep_bwd.hip, rnn_sweep_wide.hip, rnn_sweep_wide_bwd.hip, decoder_sweep.hip,
 // decoder_sweep_bwd.hip): the 32 diagnosis words that sit behind every sweep's exchange buffer, the start handshake and the
 // record a workgroup leaves when one of its bounded spins gives up.
 //
