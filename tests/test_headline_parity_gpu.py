@@ -286,6 +286,8 @@ def test_las_large_yml_training_step_with_127_decoder_steps():
         torch.cuda.synchronize()
         assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 3e-2, (float(ws.stats[0]), float(loss_r.detach()))
         assert all("wide_ws" in lw["rnn"] for lw in ws.layers)
+        assert all("wide_bwd_ws" in lw["rnn"] for lw in ws.layers), "the wide layers' BPTT must have run as the one-launch sweep"
+        model.raise_on_sweep_timeout()                     # (no hand-off of any sweep of this step gave up)
         RC._check_grads(model, leaves, 4e-1, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
                                               "attend_and_speller/decoder_layers/1/cell/kernel"), tol_l2=1.5e-1)
     finally:
