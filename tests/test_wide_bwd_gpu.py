@@ -13,7 +13,7 @@ def _rel(a, b):
     return float((a - b).norm()) / max(float(b.norm()), 1e-30)
 
 
-@pytest.mark.parametrize("B,T,masked,states", [(64, 12, False, False), (50, 9, True, True), (7, 33, True, False), (64, 3, False, True)])
+@pytest.mark.parametrize("B,T,masked,states", [(64, 12, False, False), (50, 9, True, True), (7, 33, True, False), (64, 3, False, True), (5, 2, True, True), (1, 7, False, False)])
 def test_wide_bwd_sweep_equals_the_staged_step_kernels(B, T, masked, states):
     from speech_recognition_amd import ops
     from tests.rnn_helpers import HipBiRNN
