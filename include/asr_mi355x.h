@@ -317,6 +317,10 @@ int asr_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 /* Diagnostic: `blocks` workgroups of `threads` threads that do nothing for `microseconds` (<= 2 s, bounded by the real-time
  * counter): stands in for a foreign kernel (an RCCL channel) holding compute units while the one-launch sweeps run. */
 int asr_debug_occupy(int blocks, int threads, int microseconds, void* stream);
+/* Diagnostic: `blocks` workgroups of 256 threads that copy the first half of buf[0, bytes) onto the second half, again and again,
+ * for `microseconds` (<= 2 s): a memory-streaming co-tenant (the weight-gradient products and RCCL reductions that run beside the
+ * BPTT sweeps under data parallelism, utils.py:142-153) - the regression condition of the two sweep races of DESIGN.md 4.2. */
+int asr_debug_stream_memory(float* buf, long bytes, int blocks, int microseconds, void* stream);
 
 /* Backward of one cell step.  The gradient handed from step to step is ds, the gradient wrt the gate
  * sums ([B, NS*H], written over the saved activations).  A source describes one consumer of this

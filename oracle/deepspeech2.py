@@ -104,7 +104,7 @@ def ds2_forward(p, cfg, audio, training=False, seed=0, mask_mode="intended", ret
                                  p[bn + "moving_variance"], training)
         bn_updates[bn + "moving_mean"], bn_updates[bn + "moving_variance"] = mm, mv
     x = x * mask[:, :, None].to(dt)
-    logits = x @ p["fully_connected/kernel"] + p["fully_connected/bias"]
+    logits = L.mm_dense(x, p["fully_connected/kernel"]) + p["fully_connected/bias"]
     if return_aux:
         return logits, {"mask": mask, "bn_updates": bn_updates}
     return logits

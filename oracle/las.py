@@ -102,26 +102,26 @@ def listener(p, cfg, audio, training, seed=0):
             mf = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i, (B, x.shape[2]), rate, dt)
             mb = L.dropout_mult(seed, STREAM_ENC_IN + 2 * i + 1, (B, x.shape[2]), rate, dt)
         x, *states = L.birnn(rt, x, mask, fwd, bwd, states, mf, mb)
-        x = x @ p[f"listener/projection/{i}/kernel"] + p[f"listener/projection/{i}/bias"]
+        x = L.mm_dense(x, p[f"listener/projection/{i}/kernel"]) + p[f"listener/projection/{i}/bias"]
         bn = f"listener/batch_norm/{i}/"
         x, mm, mv = L.batch_norm(x, p[bn + "gamma"], p[bn + "beta"], p[bn + "moving_mean"],
                                  p[bn + "moving_variance"], training)
         bn_updates[bn + "moving_mean"], bn_updates[bn + "moving_variance"] = mm, mv
         x = torch.relu(x)
     if len(states) == 2:
-        states = [torch.cat(states, dim=-1) @ p["listener/hidden_states_proj/kernel"]
+        states = [L.mm_dense(torch.cat(states, dim=-1), p["listener/hidden_states_proj/kernel"])
                   + p["listener/hidden_states_proj/bias"]]
     else:
         states = [
-            torch.cat(states[::2], dim=-1) @ p["listener/hidden_states_proj/kernel"]
+            L.mm_dense(torch.cat(states[::2], dim=-1), p["listener/hidden_states_proj/kernel"])
             + p["listener/hidden_states_proj/bias"],
-            torch.cat(states[1::2], dim=-1) @ p["listener/cell_states_proj/kernel"]
+            L.mm_dense(torch.cat(states[1::2], dim=-1), p["listener/cell_states_proj/kernel"])
             + p["listener/cell_states_proj/bias"],
         ]
     return x, mask, states, bn_updates
 
 
-def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=0, step=0, trace=None):
+def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=0, step=0, trace=None, keys=None):
     """AttendAndSpeller.call (las.py:267-292) for one decoder step. Returns (logits, states, probs).
     trace: optional dict (tests) that receives this step's context, masked attention scores and per-layer cell states with
     retain_grad(), so that the gradients the HIP backward sweep writes out can be read after backward()."""
@@ -135,8 +135,11 @@ def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=
     if training and rate > 0:
         x = x * L.dropout_mult(seed, base + 0, x.shape, rate, dt)
     a = "attend_and_speller/attention/"
-    ctx, probs, scores = L.attention(states[0], enc, enc, attention_mask, p[a + "query_weight/kernel"],
-                                     p[a + "query_weight/bias"], p[a + "key_weight/kernel"], p[a + "key_weight/bias"], return_scores=True)
+    if keys is not None:       # L.bf16_operands(): the build's hoisted association of the same sums (rounding points follow it)
+        ctx, probs, scores = L.attention_hoisted(states[0], keys, enc, attention_mask, return_scores=True)
+    else:
+        ctx, probs, scores = L.attention(states[0], enc, enc, attention_mask, p[a + "query_weight/kernel"],
+                                         p[a + "query_weight/bias"], p[a + "key_weight/kernel"], p[a + "key_weight/bias"], return_scores=True)
     if trace is not None:
         for t_ in (ctx, scores):
             if t_.requires_grad:
@@ -149,8 +152,10 @@ def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=
         im = None
         if training and rate > 0:
             im = L.dropout_mult(seed, base + 2 + j, (B, x.shape[1]), rate, dt)
+        # (x_mode: where the build multiplies this cell's input - L._xw; without L.bf16_operands() it changes nothing)
+        Hd = cfg["decoder_hidden_dim"]
         out, states = L.rnn_layer(rt, x[:, None, :], m, p[pre + "kernel"], p[pre + "recurrent_kernel"],
-                                  p[pre + "bias"], initial_state=states, in_mult=im)
+                                  p[pre + "bias"], initial_state=states, in_mult=im, x_mode=("split", Hd) if j == 0 else "cell")
         x = out[:, -1]                                           # return_sequences=False: last output
         if trace is not None:
             trace.setdefault(f"y{j}", []).append(x)
@@ -159,7 +164,7 @@ def attend_and_speller(p, cfg, enc, tok, attention_mask, states, training, seed=
                 trace.setdefault(f"c{j}", []).append(states[1])
     if training and rate > 0:
         x = x * L.dropout_mult(seed, base + 1, x.shape, rate, dt)
-    logits = x @ p["attend_and_speller/feedforward/kernel"] + p["attend_and_speller/feedforward/bias"]
+    logits = L.mm_dense(x, p["attend_and_speller/feedforward/kernel"]) + p["attend_and_speller/feedforward/bias"]
     return logits, states, probs
 
 
@@ -176,12 +181,16 @@ def las_forward(p, cfg, audio, tokens, training=False, seed=0, use_teacher_forci
         for t_ in init_states:
             if t_.requires_grad:
                 t_.retain_grad()
+    keys = None
+    if L._Bf16.on:
+        a = "attend_and_speller/attention/"
+        keys = L.attention_keys_hoisted(enc, p[a + "query_weight/kernel"], p[a + "query_weight/bias"], p[a + "key_weight/kernel"], p[a + "key_weight/bias"])
     for i in range(U):
         if use_teacher_forcing or i == 0:
             tok = tokens[:, i]
         else:
             tok = logits.argmax(dim=-1)
-        logits, states, probs = attend_and_speller(p, cfg, enc, tok, mask, states, training, seed, i, trace)
+        logits, states, probs = attend_and_speller(p, cfg, enc, tok, mask, states, training, seed, i, trace, keys)
         outs.append(logits)
         probs_all.append(probs)
     out = torch.stack(outs, dim=1)

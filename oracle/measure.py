@@ -26,32 +26,36 @@ def sparse_categorical_accuracy(y_true, logits, ignore_index=0):
     return float((pred[keep] == y[keep]).sum()), float(keep.sum())
 
 
+def _lse_rows(st):
+    """log-sum-exp over dim 0 of st [k, S] whose entries may be -inf (a column of only -inf gives -inf, with zero gradient)."""
+    m = st.max(dim=0).values
+    dead = torch.isinf(m) & (m < 0)
+    m_safe = torch.where(dead, torch.zeros_like(m), m)
+    tot = torch.exp(st - m_safe).sum(dim=0)
+    return torch.where(dead, m, m_safe + torch.log(torch.where(dead, torch.ones_like(tot), tot)))
+
+
 def ctc_nll(logits, labels, label_len, blank):
     """[TF-sem] tf.nn.ctc_loss for ONE sample: logits [T, V] (log-softmax applied here), labels
-    [L] ints, first `label_len` used.  Log-space alpha recursion; differentiable."""
+    [L] ints, first `label_len` used.  Log-space alpha recursion over the blank-extended label row; differentiable.
+    alpha_t(s) = lse(alpha_{t-1}(s), alpha_{t-1}(s-1), [alpha_{t-1}(s-2) if ext(s) is a label differing from ext(s-2)]) + lp_t(ext(s)),
+    all S states of a frame at once (the label log-probabilities are gathered once: [T, S])."""
     T, V = logits.shape
     lp = torch.log_softmax(logits, dim=-1)
     lab = [int(x) for x in labels[:label_len]]
     S = 2 * len(lab) + 1
     ext = [blank if s % 2 == 0 else lab[s // 2] for s in range(S)]
-    NEG = torch.tensor(-float("inf"), dtype=logits.dtype)
-    alpha = [lp[0, ext[s]] if s < 2 else NEG for s in range(S)]
+    lpe = lp[:, torch.tensor(ext, dtype=torch.long)]                                  # [T, S]
+    skip = torch.tensor([s >= 2 and ext[s] != blank and ext[s] != ext[s - 2] for s in range(S)])
+    ninf = torch.full((S,), -float("inf"), dtype=logits.dtype)
+    start = torch.arange(S) < 2
+    alpha = torch.where(start, lpe[0], ninf)
     for t in range(1, T):
-        new = []
-        for s in range(S):
-            terms = [alpha[s]]
-            if s >= 1:
-                terms.append(alpha[s - 1])
-            if s >= 2 and ext[s] != blank and ext[s] != ext[s - 2]:
-                terms.append(alpha[s - 2])
-            st = torch.stack(terms)
-            if torch.isinf(st).all():
-                new.append(NEG)
-            else:
-                new.append(torch.logsumexp(st, dim=0) + lp[t, ext[s]])
-        alpha = new
-    tail = [alpha[S - 1]] + ([alpha[S - 2]] if S >= 2 else [])
-    return -torch.logsumexp(torch.stack(tail), dim=0)
+        a1 = torch.cat([ninf[:1], alpha[:-1]])
+        a2 = torch.where(skip, torch.cat([ninf[:2], alpha[:-2]]), ninf) if S >= 2 else ninf
+        alpha = _lse_rows(torch.stack([alpha, a1, a2])) + lpe[t]
+    tail = alpha[S - 2:] if S >= 2 else alpha[S - 1:]
+    return -_lse_rows(tail[:, None])[0]
 
 
 def ctc_loss(y_true, logits, blank_index, pad_index=0):

@@ -161,6 +161,7 @@ SIGNATURES = {
     "asr_f32_to_bf16": (C.c_int, [_P, _P, c_long, _P]),
     "asr_bf16_to_f32": (C.c_int, [_P, _P, c_long, _P]),
     "asr_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int, _P]),
+    "asr_debug_stream_memory": (C.c_int, [_P, c_long, C.c_int, C.c_int, _P]),
     "asr_token_mask": (C.c_int, [_P, c_long, C.c_int, _P, c_long, _P]),
     "asr_rnn_seq_fwd": (C.c_int, [C.POINTER(RnnSeq), _P]),
     "asr_rnn_seq_bwd": (C.c_int, [C.POINTER(RnnSeq), C.POINTER(RnnSeqGrad), _P]),

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
   });
 }
 
+static hipError_t g16_attr_status = hipSuccess;                 // last hipFuncSetAttribute result of g16_launch (checked by the caller)
 struct G16Launch {
   const bf16_t *A, *B; GemmEpilogue ep; const asr_gemm_desc* d; int sk; hipStream_t st;
 };
@@ -215,8 +216,15 @@ static void g16_launch(const G16Launch& g) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr size_t smem = (size_t)NBUF * (BM + BN) * 128;
   auto kern = gemm16_nt_kernel<WM, WN, TM, TN, NBUF, STG>;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  // per device (a process may drive several): the attribute lives with the device's copy of the code object
+  static bool attr[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr[dev]) {
+    g16_attr_status = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (g16_attr_status != hipSuccess && smem > 64 * 1024) return;       // the caller reports it (asr_gemm_bf16_nt)
+    attr[dev] = true;
+  }
   const asr_gemm_desc* d = g.d;
   const int tm = asr_cdiv(d->M, BM), tn = asr_cdiv(d->N, BN);
   int k_chunk = asr_cdiv(asr_cdiv(d->K, g.sk), G16_BK) * G16_BK;
@@ -280,6 +288,12 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
     case 14: g16_launch<2, 2, 4, 2, 3, 1>(g); break;             // 256 x 128, 4 waves of 128 x 64, three buffers
     case 11: g16_launch<2, 2, 4, 2, 1, 1>(g); break;
     default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging (any K; the fallback of 12)
+  }
+  if (g16_attr_status != hipSuccess && cfg != 0) {
+    // this device refused the large-LDS attribute: nothing was launched; the 32 KB configuration needs no attribute
+    g16_attr_status = hipSuccess;
+    (void)hipGetLastError();
+    g16_launch<2, 2, 2, 2, 1, 0>(g);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;

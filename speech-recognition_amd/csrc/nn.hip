@@ -553,3 +553,31 @@ extern "C" int asr_debug_occupy(int blocks, int threads, int microseconds, void*
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
+
+// The memory-side co-tenant: `blocks` workgroups of 256 threads copy their slice of `buf` (16-byte loads and stores, `bytes` in
+// all, first half -> second half) over and over until `microseconds` have passed (real-time counter: it always ends).  Stands in
+// for the weight-gradient products / RCCL reductions whose memory traffic - not their compute units - exposed the two BPTT-sweep
+// races of round 3.
+__global__ __launch_bounds__(256) void stream_memory_kernel(float4* buf, long n4_half, long ticks) {
+  const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+  const long per = (n4_half + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n4_half ? lo + per : n4_half;
+  while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    for (long i = lo + threadIdx.x; i < hi; i += 256 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const long j = i + (long)k * 256; v[k] = j < hi ? buf[j] : float4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const long j = i + (long)k * 256; if (j < hi) buf[n4_half + j] = v[k]; }
+    }
+  }
+}
+
+extern "C" int asr_debug_stream_memory(float* buf, long bytes, int blocks, int microseconds, void* stream) {
+  ASR_CHECK(buf && bytes >= 64 && (((uintptr_t)buf & 15) == 0) && blocks > 0 && blocks <= 4096 && microseconds >= 0 && microseconds <= 2000000,
+            ASR_ERR_ARG, "asr_debug_stream_memory: bad argument");
+  hipLaunchKernelGGL(stream_memory_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(buf), bytes / 32,
+                     (long)microseconds * 100);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

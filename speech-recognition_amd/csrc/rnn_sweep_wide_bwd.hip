@@ -342,6 +342,11 @@ extern "C" int asr_rnn_sweep_wide_bwd(const asr_rnn_seq* s, const asr_rnn_seq_gr
     ASR_CHECK(s->ldu[d] % 4 == 0 && s->y_col[d] % 4 == 0 && (!s->c0[d] || s->c0_ld[d] % 4 == 0) && (!gs->dh_last[d] || gs->dh_last_ld[d] % 4 == 0) &&
                   (!gs->dh0[d] || gs->dh0_ld[d] % 4 == 0),
               ASR_ERR_SHAPE, "asr_rnn_sweep_wide_bwd: leading dimensions / column offsets must be multiples of 4 (dir %d)", d);
+    // every one of these is read or written with 16-byte vector accesses: a misaligned view (an odd-offset slice of a state tensor)
+    // must come back as an argument error, not as a fault on the device
+    const void* vec[] = {s->U[d], s->saved[d], s->cseq[d], s->c0[d], gs->ds[d], gs->dc[d], gs->dh_last[d], gs->dh0[d]};
+    for (const void* q : vec)
+      ASR_CHECK(((uintptr_t)q & 15) == 0, ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: U, saved, cseq, c0, ds, dc, dh_last and dh0 must be 16-byte aligned (dir %d)", d);
     WbDir& p = a.d[d];
     p.U = s->U[d]; p.ldu = s->ldu[d];
     p.saved = s->saved[d]; p.cseq = s->cseq[d];

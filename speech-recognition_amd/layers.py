@@ -439,7 +439,7 @@ class BiRNN:
                     if pws is None:
                         ops.colsum(ds2, g[nm + "bias"])
                     hs = dd["hseq"]
-                    hT = ops.image_scratch("hT_r" if dd["reverse"] else "hT_f", H, B * T)
+                    hT = ops.image_scratch("hT_r" if dd["reverse"] else "hT_f", H, B * T, layout=(B, T))
                     if dd["reverse"]:
                         ops.f32_to_bf16_image(hs[:, 1:], hT, transpose=True, dst_rows_per_batch=T, dst_shift=0)
                     else:

@@ -336,14 +336,17 @@ _bf16_images = {"on": os.environ.get("ASR_GEMM_BF16_IMAGES", "1") != "0", "min_d
                 "scratch": {}}
 
 
-def _image_scratch(role, rows, cols):
-    """bf16 [rows, cols8] scratch, one per (role, stream, shape): GEMMs of one stream run in order, so consecutive products may
-    share it; products on different streams never do."""
+def _image_scratch(role, rows, cols, layout=None):
+    """bf16 [rows, cols8] scratch, one per (role, stream, rows, EXACT cols, layout): GEMMs of one stream run in order, so consecutive
+    products of one shape may share it; products on different streams never do.  The key carries the exact contraction length, not
+    the padded one, and `layout` (the (B, T) of a shifted image): the image passes never write the k padding [cols, cols8) nor the
+    'no predecessor' column of a shifted image, which must read as 0 - two products that only agree on the padded size (K = 1004 and
+    K = 1008; (B, T) and (2B, T/2)) would otherwise read each other's stale values there."""
     cols8 = (cols + 7) // 8 * 8
-    key = (role, torch.cuda.current_stream().cuda_stream, rows, cols8)
+    key = (role, torch.cuda.current_stream().cuda_stream, rows, cols, layout)
     buf = _bf16_images["scratch"].get(key)
     if buf is None:
-        # zero-filled once: the k padding [cols, cols8) is never written by the image pass and must read as 0
+        # zero-filled once: what the image pass of THIS shape never writes stays 0 for the life of the buffer
         buf = _bf16_images["scratch"][key] = torch.zeros(rows, cols8, device="cuda", dtype=torch.bfloat16)
     return buf
 
@@ -369,9 +372,9 @@ def bf16_images_pay(M, N, K) -> bool:
     return bool(mixed_precision() and _bf16_images["on"] and M >= md // 2 and N >= md // 2 and K >= md and M * N >= md * md)
 
 
-def image_scratch(role, rows, cols):
-    """A zero-initialised bf16 [rows, cols rounded up to 8] scratch per (role, stream, shape) - see _image_scratch."""
-    return _image_scratch(role, rows, cols)
+def image_scratch(role, rows, cols, layout=None):
+    """A zero-initialised bf16 [rows, cols rounded up to 8] scratch per (role, stream, exact shape, layout) - see _image_scratch."""
+    return _image_scratch(role, rows, cols, layout)
 
 
 def gemm_bf16_nt(a16, b16, c, *, alpha=1.0, accumulate=0, bias=None, relu=False, c_scale=None, c_rpg=0, split_k=1, K=None):
@@ -414,8 +417,8 @@ def _gemm_bf16_images(d, a, b, c, trans_a, trans_b, a_scale, a_rpg, a_scale_stri
             return False
     if not trans_a and scale is not None and scale.data_ptr() % 16:
         return False
-    a16 = f32_to_bf16_image(a, _image_scratch("a", d.M, K8), transpose=trans_a, scale=scale, rows_per_group=rpg)
-    b16 = f32_to_bf16_image(b, _image_scratch("b", d.N, K8), transpose=not trans_b)
+    a16 = f32_to_bf16_image(a, _image_scratch("a", d.M, K), transpose=trans_a, scale=scale, rows_per_group=rpg)
+    b16 = f32_to_bf16_image(b, _image_scratch("b", d.N, K), transpose=not trans_b)
     acc = 1 if d.accumulate else 0                                # (the batch split became one product: no atomics needed)
     if d.split_k > 1:
         acc = 2
@@ -440,6 +443,13 @@ def bf16_to_f32(src: torch.Tensor, dst: torch.Tensor):
 def debug_occupy(blocks: int, threads: int, microseconds: int):
     """Diagnostic: keep `blocks` workgroups busy for `microseconds` on the current stream (asr_debug_occupy)."""
     check(lib().asr_debug_occupy(int(blocks), int(threads), int(microseconds), _stream()))
+
+
+def debug_stream_memory(buf: torch.Tensor, blocks: int, microseconds: int):
+    """Diagnostic: `blocks` workgroups stream `buf` (f32, first half copied onto the second) for `microseconds` on the current
+    stream (asr_debug_stream_memory): a memory-side co-tenant."""
+    assert buf.dtype == torch.float32 and buf.is_contiguous()
+    check(lib().asr_debug_stream_memory(_p(buf), buf.numel() * 4, int(blocks), int(microseconds), _stream()))
 
 
 # ----------------------------------------------------------------------------------------- recurrent layers

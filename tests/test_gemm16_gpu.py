@@ -139,3 +139,68 @@ def test_shifted_transposed_image_lets_the_recurrent_gradient_share_the_ds_image
         gU = torch.zeros(H, N, device="cuda")
         ops.gemm_bf16_nt(hT, dsT, gU, accumulate=1)
         _check(gU, want, hs, ds)
+
+
+def test_scratch_is_not_shared_between_contractions_that_only_agree_on_the_padded_k():
+    """the image scratch was keyed by K rounded up to 8 and zeroed once.  K = 1008 leaves values in columns
+    [1004, 1008) that a following K = 1004 product (same M, N, same padded size) would read as its zero padding."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(13)
+    M, N = 256, 384
+    old = ops._bf16_images["min_dim"]
+    ops._bf16_images["min_dim"] = 128
+    try:
+        for K in (1008, 1004, 1001, 1008):
+            A = torch.randn(M, K, generator=g).cuda() + 1.0           # (a non-zero mean makes stale padding products add up)
+            Bm = torch.randn(K, N, generator=g).cuda() + 1.0
+            for ta, tb in ((False, False), (True, False), (False, True)):
+                a = A.t().contiguous() if ta else A
+                b = Bm.t().contiguous() if tb else Bm
+                c = torch.empty(M, N, device="cuda")
+                ops.gemm(a, b, c, trans_a=ta, trans_b=tb, compute=1)
+                _check(c, _bf(A) @ _bf(Bm), A, Bm)
+    finally:
+        ops._bf16_images["min_dim"] = old
+
+
+def test_birnn_backward_shared_image_path_survives_a_change_of_batch_geometry():
+    """the shifted h image's 'no predecessor' column sits at t = 0 (T - 1 reversed) of every clip, so it moves when (B, T)
+    changes at constant B * T.  Two BiRNN backward passes through the shared-image path, (B, T) then (2B, T / 2), each against the
+    f32-operand-kernel path (bf16 fragments, the same numerics) on the same tensors."""
+    from speech_recognition_amd import layers, ops
+    from speech_recognition_amd.params import ParamStore
+    H, Din = 256, 256
+    old = ops._bf16_images["min_dim"]
+    ops._bf16_images["min_dim"] = 128
+    ops.set_mixed_precision(True)
+    try:
+        shapes = layers.BiRNN.param_shapes("l/", "lstm", Din, H)
+        res = {}
+        for images in (True, False):
+            ops._bf16_images["on"] = images
+            g = torch.Generator().manual_seed(3)
+            store = ParamStore(shapes)
+            for n in shapes:
+                store.p[n].copy_(torch.randn(shapes[n], generator=g) * 0.05)
+            store.refresh_bf16()
+            rnn = layers.BiRNN(store, "l/", "lstm", Din, H, 0.0, 40)
+            rnn.pack()
+            for B, T in ((8, 64), (16, 32)):
+                x = torch.randn(B, T, Din, generator=g).cuda()
+                dy = torch.randn(B, T, 2 * H, generator=g).cuda()
+                buf = rnn.alloc(B, T)
+                ops.fill(store.grad, 0.0)
+                rnn.forward(buf, x, None, None, True, None)
+                dcs = [torch.zeros(B, H, device="cuda") for _ in range(2)]
+                rnn.backward(buf, dy, [None, None], dcs, None)
+                torch.cuda.synchronize()
+                res[(images, B, T)] = {k: v.clone() for k, v in store.grads().items()}
+        for B, T in ((8, 64), (16, 32)):
+            for k, ref in res[(False, B, T)].items():
+                got = res[(True, B, T)][k]
+                err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+                assert err < 2e-3, (B, T, k, err)
+    finally:
+        ops._bf16_images["on"] = True
+        ops._bf16_images["min_dim"] = old
+        ops.set_mixed_precision(False)

@@ -28,12 +28,11 @@ pytestmark = pytest.mark.gpu
 
 
 # ---------------------------------------------------------------------------------------------- the headline step, batch 32
-def test_las_small_yml_headline_step_batch_32_against_the_oracle():
+@pytest.fixture(scope="module")
+def headline():
     """BASELINE configs[1] exactly as bench.py runs it (B = 32, 10 s, U = 64, SpecAugment + delta on the GPU, dropout 0.15, teacher
-    forcing): two 16-row batch tiles x H = 256 through the encoder sweeps (forward + BPTT) and both decoder sweeps."""
-    from speech_recognition_amd import layers, ops
+    forcing) and the float64 oracle's loss / accuracy counts / gradients for it, computed once for the tests below."""
     from speech_recognition_amd.configs import get_model_config
-    assert layers.PERSISTENT_RNN
     B = 32
     mc = RC._yaml("las_small.yml")
     dc, plan = RC._frontend()
@@ -43,32 +42,84 @@ def test_las_small_yml_headline_step_batch_32_against_the_oracle():
     feats, ref_feats = RC._features(plan, dc, audio, n, seed)
     model = get_model_config(os.path.join(RC.CONFIGS, "las_small.yml")).create_model(seed=7)
     model.build(80, 3)
-    model.state[1] = seed
     leaves = RC._leaves(model)
     t = torch.from_numpy(toks)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
     loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
     loss_r.backward()
     correct_r, count_r = OM.sparse_categorical_accuracy(t[:, 1:], logits_r.detach(), 0)
+    del model
+    return dict(B=B, seed=seed, feats=feats, t=t, leaves=leaves, logits=logits_r.detach(), loss=float(loss_r.detach()), correct=correct_r, count=count_r)
 
-    ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+
+def _headline_step(h, beside=None):
+    """One forward + loss + backward of the headline batch on a fresh las_small.yml model (same initial weights as the fixture's:
+    seed 7); `beside(stream)` may start foreign work on a side stream first.  Checks everything against the oracle."""
+    from speech_recognition_amd import layers, ops
+    from speech_recognition_amd.configs import get_model_config
+    assert layers.PERSISTENT_RNN
+    B, feats, t = h["B"], h["feats"], h["t"]
+    model = get_model_config(os.path.join(RC.CONFIGS, "las_small.yml")).create_model(seed=7)
+    model.build(80, 3)
+    model.state[1] = h["seed"]
+    ws, labels = model.train_workspace(B, feats.shape[1], t.shape[1])
     assert (ws.B, ws.T2, ws.U) == (32, 249, 64)
     model.set_targets(ws, t.cuda(), labels)
     ops.fill(model.store.grad, 0.0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    if beside is not None:
+        with torch.cuda.stream(side):
+            beside()
     model.forward_ws(ws, feats, True, True)
-    assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), logits_r, 1e-3, "las_small B=32 training logits")
+    assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), h["logits"], 1e-3, "las_small B=32 training logits")
     model.loss_and_grad(ws, labels)
     model.backward_ws(ws, feats)
     torch.cuda.synchronize()
     st = ws.stats.cpu().numpy()
-    assert abs(st[0] - float(loss_r.detach())) < 1e-3, (st[0], float(loss_r.detach()))
-    assert st[2] == count_r and abs(st[1] - correct_r) <= 2
+    assert abs(st[0] - h["loss"]) < 1e-3, (st[0], h["loss"])
+    assert st[2] == h["count"] and abs(st[1] - h["correct"]) <= 2
     assert all(f and b for f, b in RC._persistent_layers(ws)), "encoder: the forward and BPTT sweeps the benchmark times"
     assert getattr(ws, "_sweep_ok", False), "decoder: the forward sweep the benchmark times"
     assert getattr(ws, "_sweep_bwd_ok", False), "decoder: the backward sweep the benchmark times"
     assert not ops.decoder_sweep_error(ws.dsweep_ws) and not ops.decoder_sweep_error(ws.dsweep_bwd_ws)
     assert float(model.store.err_flag[0]) == 0.0
-    RC._check_grads(model, leaves, 5e-3, RC.LAS_NAMED)
+    model.raise_on_sweep_timeout()
+    RC._check_grads(model, h["leaves"], 5e-3, RC.LAS_NAMED)
+    return model, ws
+
+
+def test_las_small_yml_headline_step_batch_32_against_the_oracle(headline):
+    """Two 16-row batch tiles x H = 256 through the encoder sweeps (forward + BPTT) and both decoder sweeps: loss (1e-3), accuracy
+    counts and every gradient."""
+    _headline_step(headline)
+
+
+def test_headline_step_beside_a_memory_streaming_co_tenant(headline):
+    """The regression condition of the two BPTT-sweep races of round 3 (ds written in place one step late; the
+    exchange slot re-armed one step early) - both showed only when OTHER kernels' memory traffic changed the timing of the sweeps'
+    hand-offs, never alone.  64 foreign workgroups stream 1 GiB back and forth (16-byte loads and stores, no compute) on a side
+    stream for the whole forward and backward pass, so a quarter of the compute units carry uneven load and every hand-off crosses a
+    busy fabric; the step must neither time out nor move any gradient beyond the f32-vs-f64 tolerances of the quiet run."""
+    from speech_recognition_amd import ops
+    buf = torch.empty(1 << 28, device="cuda", dtype=torch.float32)          # 1 GiB: far beyond the L2s, inside the Infinity Cache's reach only in part
+    _headline_step(headline, beside=lambda: ops.debug_stream_memory(buf, 64, 400000))
+    torch.cuda.synchronize()
+    del buf
+
+
+def test_headline_step_with_weight_gradients_released_beside_the_sweeps(headline):
+    """ASR_OVERLAP=1 (layers.Overlap; off by default because it is slower): every stage's weight-gradient products run on a side
+    stream BESIDE the next one-launch sweep - the very arrangement that exposed the two races.  Same checks as the quiet run."""
+    from speech_recognition_amd import layers
+    old = layers.Overlap.enabled
+    layers.Overlap.enabled = True
+    try:
+        model, ws = _headline_step(headline)
+        assert model._ov.on, "the overlap scheduler must have been active"
+    finally:
+        layers.Overlap.enabled = old
 
 
 def test_las_small_yml_15_second_clips_run_both_decoder_sweeps():
@@ -254,7 +305,7 @@ def test_las_large_layer_wide_sweeps_and_staged_backward_at_full_sequence_geomet
 def test_las_large_yml_training_step_with_127_decoder_steps():
     """las_large.yml under mixed precision (BASELINE configs[4]) with the benchmark's decoder length: 128-token rows = U = 127
     steps of {attention over T', two 1024-wide LSTM cells, Dense(16000)} on the per-step kernels, B = 18, 4 s clips (T' = 99).
-    Loss within 3e-2, gradients within the mixed-precision bounds of test_las_large_yml_training_step_wide_kernels."""
+    Against the oracle's bf16-operand mode: logits 3e-3, loss 2e-3, gradients relative L2 1e-2 (max-norm 5e-2: ReLU kinks)."""
     from speech_recognition_amd import ops
     from speech_recognition_amd.configs import get_model_config
     mc = RC._yaml("las_large.yml")
@@ -271,7 +322,8 @@ def test_las_large_yml_training_step_with_127_decoder_steps():
         model.state[1] = seed
         leaves = RC._leaves(model)
         t = torch.from_numpy(toks)
-        logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+        with OL.bf16_operands():                             # the oracle rounds the same operands to bf16 (oracle/layers.py)
+            logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
         loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
         loss_r.backward()
         ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
@@ -280,15 +332,78 @@ def test_las_large_yml_training_step_with_127_decoder_steps():
         ops.fill(model.store.grad, 0.0)
         model.pack_weights()
         model.forward_ws(ws, feats, True, True)
-        assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), logits_r, 5e-2, "las_large U=127 training logits")
+        assert_close(ws.logits.view(ws.U, B, -1).permute(1, 0, 2), logits_r, 3e-3, "las_large U=127 training logits")
         model.loss_and_grad(ws, labels)
         model.backward_ws(ws, feats)
         torch.cuda.synchronize()
-        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 3e-2, (float(ws.stats[0]), float(loss_r.detach()))
+        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 2e-3, (float(ws.stats[0]), float(loss_r.detach()))
         assert all("wide_ws" in lw["rnn"] for lw in ws.layers)
         assert all("wide_bwd_ws" in lw["rnn"] for lw in ws.layers), "the wide layers' BPTT must have run as the one-launch sweep"
         model.raise_on_sweep_timeout()                     # (no hand-off of any sweep of this step gave up)
-        RC._check_grads(model, leaves, 4e-1, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
-                                              "attend_and_speller/decoder_layers/1/cell/kernel"), tol_l2=1.5e-1)
+        worst = RC._check_grads(model, leaves, 5e-2, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
+                                                      "attend_and_speller/decoder_layers/1/cell/kernel"), tol_l2=1e-2)
+        print(f"las_large U=127 mixed: worst max-norm gradient error {worst}")
     finally:
         ops.set_mixed_precision(False)
+
+
+def test_las_large_yml_whole_step_at_the_full_baseline_geometry():
+    """BASELINE configs[4] exactly as bench.py runs it: las_large.yml under mixed precision, B = 64, 20 s clips (T' = 499), 128-token
+    rows (U = 127), SpecAugment + dropout on, ragged clips and token rows.  The float64 oracle of this step is hours of CPU, so the
+    whole step is checked through properties: every wide layer ran BOTH one-launch sweeps (forward and BPTT), no hand-off of any sweep
+    gave up, everything is finite, and loss and EVERY gradient agree with the same step on the per-step kernels
+    (ASR_PERSISTENT_RNN=0: no sweep of any kind; same weights, same dropout masks, same bf16 operand rounding - the paths differ in
+    f32 summation order and in the bf16 partial sums of the wide BPTT exchange): loss 5e-3, gradients relative L2 3e-2 per tensor.
+    The per-step kernels themselves are pinned against the oracle at B = 18 (tests/test_real_configs_gpu.py) and layer-wise at this
+    geometry (test_las_large_layer_wide_sweeps_and_staged_backward_at_full_sequence_geometry)."""
+    from speech_recognition_amd import layers, ops
+    from speech_recognition_amd.configs import get_model_config
+    mc = RC._yaml("las_large.yml")
+    _, plan = RC._frontend()
+    seed, B = 2718, 64
+    audio, n = RC._audio(B, 20.0, short={3: 12.9, 17: 5.5, 40: 19.0, 63: 8.25}, seed=8)
+    toks = RC._tokens(B, 128, mc["vocab_size"], ragged={5: 77, 11: 30, 50: 127})
+    feats = plan(torch.from_numpy(audio).cuda(), torch.from_numpy(n).cuda(), plan.num_frames(audio.shape[1]),
+                 seed=torch.tensor([seed], dtype=torch.int32, device="cuda"))
+    t = torch.from_numpy(toks)
+    res = {}
+    ops.set_mixed_precision(True)
+    old = layers.PERSISTENT_RNN
+    try:
+        for sweeps in (True, False):
+            layers.PERSISTENT_RNN = sweeps
+            model = get_model_config(os.path.join(RC.CONFIGS, "las_large.yml")).create_model(seed=13)
+            model.build(80, 3)
+            model.state[1] = seed
+            ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
+            assert (ws.B, ws.T2, ws.U) == (64, 499, 127)
+            model.set_targets(ws, t.cuda(), labels)
+            ops.fill(model.store.grad, 0.0)
+            model.pack_weights()
+            model.forward_ws(ws, feats, True, True)
+            model.loss_and_grad(ws, labels)
+            model.backward_ws(ws, feats)
+            torch.cuda.synchronize()
+            model.raise_on_sweep_timeout()
+            assert float(model.store.err_flag[0]) == 0.0
+            ran = [("wide_ws" in lw["rnn"], "wide_bwd_ws" in lw["rnn"]) for lw in ws.layers]
+            assert ran == [(sweeps, sweeps)] * len(ws.layers), ran
+            loss = float(ws.stats[0])
+            grads = model.store.grads()
+            assert np.isfinite(loss) and all(bool(torch.isfinite(g).all()) for g in grads.values())
+            res[sweeps] = (loss, grads, ws.stats.cpu().numpy().copy())
+            del model, ws, labels, grads
+            torch.cuda.empty_cache()
+    finally:
+        layers.PERSISTENT_RNN = old
+        ops.set_mixed_precision(False)
+    (la, ga, sa), (lb, gb, sb) = res[True], res[False]
+    print(f"las_large B=64 U=127: loss sweeps {la:.5f} per-step {lb:.5f}")
+    assert abs(la - lb) < 5e-3, (la, lb)
+    assert sa[2] == sb[2]                                            # the same number of target tokens was scored
+    bad = []
+    for k, ref in gb.items():
+        l2 = float((ga[k].double() - ref.double()).norm()) / max(float(ref.double().norm()), 1e-12)
+        if not l2 < 3e-2:
+            bad.append(f"{k}: relative L2 {l2:.2e}")
+    assert not bad, "; ".join(bad)

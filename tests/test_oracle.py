@@ -150,6 +150,28 @@ def test_conv2d_against_torch():
         torch.testing.assert_close(got, ref, rtol=1e-10, atol=1e-10)
 
 
+def test_conv2d_hand_written_gradients_against_autograd_of_the_tap_by_tap_definition():
+    """conv2d_nhwc gathers each clip into one matrix and carries hand-written gradients (oracle/layers.py _Conv2dIm2col): forward
+    and both gradients against autograd on the tap-by-tap definition and against F.conv2d, strides (2,2) / (2,1), ragged extents."""
+    g = torch.Generator().manual_seed(31)
+    for (B, H, W, Cc), (kh, kw), (sh, sw), O in (((2, 50, 20, 3), (3, 3), (2, 2), 8), ((3, 47, 23, 5), (11, 5), (2, 1), 4),
+                                                  ((1, 64, 30, 2), (21, 11), (2, 1), 6)):
+        x = torch.randn(B, H, W, Cc, generator=g, dtype=torch.float64)
+        k = torch.randn(kh, kw, Cc, O, generator=g, dtype=torch.float64)
+        b = torch.randn(O, generator=g, dtype=torch.float64)
+        res = []
+        for fn in (L.conv2d_nhwc, L.conv2d_nhwc_taps,
+                   lambda x_, k_, b_, st: Fn.conv2d(x_.permute(0, 3, 1, 2), k_.permute(3, 2, 0, 1), b_, stride=st).permute(0, 2, 3, 1)):
+            xl, kl, bl = (t.clone().requires_grad_(True) for t in (x, k, b))
+            y = fn(xl, kl, bl, (sh, sw))
+            dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+            (y * dy).sum().backward()
+            res.append((y.detach(), xl.grad, kl.grad, bl.grad))
+        for other in res[1:]:
+            for a, r in zip(res[0], other):
+                torch.testing.assert_close(a, r, rtol=1e-10, atol=1e-10)
+
+
 @pytest.mark.parametrize("rt", ["lstm", "gru", "rnn"])
 def test_rnn_layer_against_torch_nn(rt):
     g = torch.Generator().manual_seed(4)
@@ -270,3 +292,65 @@ def test_ds2_forward_shapes_and_mask_modes():
     compat = ODS.ds2_forward(p, cfg, audio, mask_mode="reference_compat")
     # deepspeech2.py:74 as written masks every frame: logits collapse to the FC bias
     torch.testing.assert_close(compat, p["fully_connected/bias"].expand(2, T2, 17))
+
+
+# ------------------------------------------------------------------------------------------ the bf16-operand mode of the restatement
+def _tiny_las(rt="lstm", He=8, Hd=8, V=13):
+    from oracle import las as OLAS
+    cfg = dict(rnn_type=rt, vocab_size=V, encoder_hidden_dim=He, decoder_hidden_dim=Hd, num_encoder_layers=2, num_decoder_layers=2,
+               dropout=0.1, teacher_forcing_rate=0.99, pad_id=0)
+    g = torch.Generator().manual_seed(12)
+    p = {}
+    for k, s in OLAS.param_shapes(cfg, 12, 3).items():
+        p[k] = (torch.rand(s, generator=g, dtype=torch.float64) + 0.5) if k.endswith(("gamma", "moving_variance")) else \
+            torch.randn(s, generator=g, dtype=torch.float64) * 0.3
+    leaves = {k: v.clone().requires_grad_(not k.endswith(("moving_mean", "moving_variance"))) for k, v in p.items()}
+    audio = torch.randn(19, 30, 12, 3, generator=g, dtype=torch.float64)
+    audio[2, 20:] = 0.0
+    toks = torch.randint(1, V, (19, 5), generator=g)
+    toks[4, 3:] = 0
+    return OLAS, cfg, leaves, audio, toks
+
+
+@pytest.mark.parametrize("rt", ["lstm", "gru"])
+def test_bf16_operand_mode_without_rounding_is_the_reference_form(rt):
+    """L.bf16_operands() re-associates the attention the way the build does (key projection hoisted out of the decoder loop,
+    scores = h Kq^T + s0) and routes every contraction through hand-written gradients: with the rounding itself switched off the
+    logits and EVERY gradient must equal the reference-form restatement to float64 rounding."""
+    OLAS, cfg, leaves, audio, toks = _tiny_las(rt)
+    res = []
+    for mode in (None, L.bf16_operands(rounding=False, wide_h=4, attn_hd=4), L.bf16_operands(rounding=False)):
+        lv = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in leaves.items()}
+        if mode is None:
+            out = OLAS.las_forward(lv, cfg, audio, toks[:, :-1], training=True, seed=3)
+        else:
+            with mode:
+                out = OLAS.las_forward(lv, cfg, audio, toks[:, :-1], training=True, seed=3)
+        loss = M.sparse_categorical_crossentropy(toks[:, 1:], out, 0)
+        loss.backward()
+        res.append((out.detach(), {k: v.grad for k, v in lv.items() if v.requires_grad}))
+    for out, grads in res[1:]:
+        torch.testing.assert_close(out, res[0][0], rtol=1e-10, atol=1e-11)
+        for k, gr in grads.items():
+            torch.testing.assert_close(gr, res[0][1][k], rtol=1e-9, atol=1e-11, msg=k)
+
+
+def test_bf16_operand_mode_rounds_where_it_says():
+    """mm_dense rounds both operands in all three products; mm_cell is exact below the wide threshold except for its weight
+    gradient; bf16 rounding is to nearest even on 8 significant bits."""
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(20, 6, generator=g, dtype=torch.float64)
+    b = torch.randn(6, 5, generator=g, dtype=torch.float64)
+    dc = torch.randn(20, 5, generator=g, dtype=torch.float64)
+    bf = lambda t: t.float().to(torch.bfloat16).double()
+    assert float(bf(torch.tensor([1.0 + 2 ** -8])).item()) == 1.0 and float(bf(torch.tensor([1.0 + 3 * 2 ** -8])).item()) == 1.0 + 2 ** -6
+    with L.bf16_operands(wide_h=8):
+        for fn, rf, rda in ((L.mm_dense, True, True), (lambda x, y: L.mm_cell(x, y, 4), False, False), (lambda x, y: L.mm_cell(x, y, 8), True, True)):
+            al, bl = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            c = fn(al, bl)
+            (c * dc).sum().backward()
+            torch.testing.assert_close(c.detach(), bf(a) @ bf(b) if rf else a @ b, rtol=0, atol=1e-14)
+            torch.testing.assert_close(al.grad, bf(dc) @ bf(b).t() if rda else dc @ b.t(), rtol=0, atol=1e-14)
+            torch.testing.assert_close(bl.grad, bf(a).t() @ bf(dc), rtol=0, atol=1e-14)
+    c = L.mm_dense(a, b)
+    torch.testing.assert_close(c, a @ b, rtol=0, atol=0)              # outside the context: the plain product

@@ -13,8 +13,10 @@ parity through the kernels the benchmark actually times:
 Tolerances (f32 kernels against a float64 oracle; the loss bound is north_star's): loss 1e-3 absolute, logits 1e-3 of
 their range, gradients 5e-3 of each tensor's largest entry at full size (f32 sums over ~10^5 terms), 2e-3 on the small
 models; las_large (2048-wide ReLU(BN) layers): relative L2 5e-3 with the entry-wise bound at 5e-2 (see _check_grads);
-mixed precision: bf16 operand rounding, L2 1.5e-1 (measured 6-9 %).
+mixed precision: against the oracle's bf16-operand mode (oracle/layers.py bf16_operands: the same operands rounded at the same
+places, forward and backward) - logits 3e-3, loss 2e-3, gradients relative L2 1e-2.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -25,6 +27,7 @@ import yaml
 from oracle import deepspeech2 as ODS
 from oracle import features as OF
 from oracle import las as OLAS
+from oracle import layers as OL
 from oracle import measure as OM
 from tests.util import assert_close
 
@@ -220,16 +223,19 @@ def test_las_small_yml_reference_fixture_batch():
 
 
 # ---------------------------------------------------------------------------------------------- deepspeech.yml, real geometry
-def test_deepspeech_yml_training_step_at_full_geometry():
-    """BASELINE configs[3] geometry (15 s clips, 96 CTC labels, blank 14, mask mode 'intended') at batch 2, one clip shorter."""
+@pytest.mark.parametrize("B", [2, 16])
+def test_deepspeech_yml_training_step_at_full_geometry(B):
+    """BASELINE configs[3] geometry (15 s clips, 96 CTC labels, blank 14, mask mode 'intended') at batch 2 and at the configuration's
+    own per-GPU batch 16 (the convolutions' tile / K-partition choices depend on B: VERDICT r3 weak 2), ragged clips and label rows:
+    features, logits, per-sample CTC loss, loss (1e-3) and EVERY gradient against the float64 oracle."""
     from speech_recognition_amd import ops
     from speech_recognition_amd.configs import get_model_config
     mc = _yaml("deepspeech.yml")
     dc, plan = _frontend()
     seed = 777
-    B = 2
-    audio, n = _audio(B, 15.0, short={1: 11.0}, seed=99)
-    toks = _tokens(B, 96, mc["vocab_size"], ragged={1: 70})
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    audio, n = _audio(B, 15.0, short={1: 11.0} if B == 2 else {1: 11.0, 6: 4.2, 15: 14.1}, seed=99)
+    toks = _tokens(B, 96, mc["vocab_size"], ragged={1: 70} if B == 2 else {1: 70, 6: 20, 11: 95})
     feats, ref_feats = _features(plan, dc, audio, n, seed)
     assert tuple(feats.shape) == (B, 1499, 80, 3)
     model = get_model_config(os.path.join(CONFIGS, "deepspeech.yml")).create_model(seed=3)
@@ -253,6 +259,7 @@ def test_deepspeech_yml_training_step_at_full_geometry():
     assert abs(float(ws.stats[0]) - float(loss_r.detach())) < 1e-3, (float(ws.stats[0]), float(loss_r))
     assert_close(ws.per_sample, per_r, 1e-4, "per-sample CTC loss")
     assert all(f and b for f, b in _persistent_layers(ws)), "the GRU layers must run the persistent kernels the benchmark times"
+    assert float(model.store.err_flag[0]) == 0.0, "no hand-off of any sweep of this step gave up"
     _check_grads(model, leaves, 5e-3, ("fully_connected/kernel", "convolution/conv_layers/0/kernel", "convolution/conv_layers/2/kernel",
                                        "recurrent/rnn_layers/0/forward_rnn/cell/kernel", "recurrent/rnn_layers/6/backward_rnn/cell/recurrent_kernel",
                                        "recurrent/batch_norm/3/gamma"))
@@ -280,7 +287,10 @@ def test_las_large_yml_training_step_wide_kernels(mixed):
         model.state[1] = seed
         leaves = _leaves(model)
         t = torch.from_numpy(toks)
-        logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
+        # mixed precision: the oracle rounds the operands of the same contractions to bf16, forward and backward (OL.bf16_operands),
+        # so what is left between the two is f32-vs-f64 accumulation and the bf16 partial sums of the wide BPTT exchange
+        with (OL.bf16_operands() if mixed else contextlib.nullcontext()):
+            logits_r = OLAS.las_forward(leaves, mc, ref_feats, t[:, :-1], training=True, seed=seed, use_teacher_forcing=True)
         loss_r = OM.sparse_categorical_crossentropy(t[:, 1:], logits_r, 0)
         loss_r.backward()
         ws, labels = model.train_workspace(B, feats.shape[1], toks.shape[1])
@@ -289,20 +299,21 @@ def test_las_large_yml_training_step_wide_kernels(mixed):
         model.pack_weights()
         model.forward_ws(ws, feats, True, True)
         out = ws.logits.view(ws.U, B, -1).permute(1, 0, 2)
-        assert_close(out, logits_r, 5e-2 if mixed else 1e-3, "las_large training logits")
+        assert_close(out, logits_r, 3e-3 if mixed else 1e-3, "las_large training logits")
         model.loss_and_grad(ws, labels)
         model.backward_ws(ws, feats)
         torch.cuda.synchronize()
-        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < (3e-2 if mixed else 1e-3), (float(ws.stats[0]), float(loss_r))
+        assert abs(float(ws.stats[0]) - float(loss_r.detach())) < (2e-3 if mixed else 1e-3), (float(ws.stats[0]), float(loss_r))
         assert not any(f or b for f, b in _persistent_layers(ws)), "H = 1024 is beyond the f32 sweeps: the step kernels run"
         # ... except the forward recurrence under mixed precision, which runs as the weights-resident bf16 sweep (rnn_sweep_wide.hip)
         assert all(("wide_ws" in lw["rnn"]) == mixed for lw in ws.layers), [list(lw["rnn"]) for lw in ws.layers]
-        # f32: L2 at rounding level, entry-wise bound loosened for the ReLU kinks (see _check_grads).  mixed: every dense contraction
-        # and recurrent product rounds its operands to bf16 (2^-8 relative); through four BiLSTM layers, BatchNorm backward (which
-        # cancels the common mode of its input) and the attention the measured relative L2 error of the gradients is 6-9 %
-        _check_grads(model, leaves, 4e-1 if mixed else 5e-2, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
-                                                               "attend_and_speller/decoder_layers/1/cell/kernel"),
-                     tol_l2=1.5e-1 if mixed else 5e-3)
+        # f32: L2 at rounding level, entry-wise bound loosened for the ReLU kinks (see _check_grads).  mixed, against the oracle that
+        # rounds the same operands (round 3 compared with the unrounded oracle and needed 4e-1 / 1.5e-1): relative L2 1e-2, max-norm
+        # 5e-2 as for f32 (the same ReLU kinks; a bf16 operand within f32 rounding of a rounding boundary may flip as well)
+        worst = _check_grads(model, leaves, 5e-2, ("listener/encoder_layers/1/forward_rnn/cell/recurrent_kernel",
+                                                    "attend_and_speller/decoder_layers/1/cell/kernel"),
+                             tol_l2=1e-2 if mixed else 5e-3)
+        print(f"las_large B={B} mixed={mixed}: worst max-norm gradient error {worst}")
     finally:
         ops.set_mixed_precision(False)
 
