@@ -1,4 +1,4 @@
-// Status plumbing of libasr_mi355x: last-error string and version.
+// Runtime plumbing of libasr_mi355x: runtime-error hand-over and the ABI struct sizes.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -7,17 +7,7 @@
 
 #include "../../include/asr_mi355x.h"
 
-static thread_local char g_err[512] = "";
-
-void asr_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
-extern "C" const char* asr_last_error(void) { return g_err; }
-extern "C" int asr_version(void) { return 100; }
+// (asr_set_error / asr_last_error / asr_version live in status.cpp: plain C++, shared with the sanitizer build of the host parsers)
 
 // Called once by the binding after the library (and the process's HIP runtime) is loaded: reports - and thereby clears - whatever
 // error an earlier runtime call of this thread left behind, so that the first ASR_LAUNCH_CHECK does not blame a launch for it.

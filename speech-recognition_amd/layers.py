@@ -273,7 +273,7 @@ class BiRNN:
         # wide layers under mixed precision: the BPTT sweep with resident bf16 blocks of U (rnn_sweep_wide_bwd.hip).  It reads the saved
         # activations while it writes ds (the workgroups of a grid row repeat the gate gradients, each at its own pace): ds out of place
         buf["wide_bwd_mode"] = bool(PERSISTENT_RNN and WIDE_SWEEP_BWD and self.recurrent_dropout == 0 and T >= 2 and not buf["coef_mode"]
-                                    and ops.rnn_sweep_wide_bwd_supported(rt, B, T, H, 2)
+                                    and ops.device_exclusive() and ops.rnn_sweep_wide_bwd_supported(rt, B, T, H, 2)
                                     and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
         if buf["wide_bwd_mode"]:
             for dd in buf["dirs"]:
@@ -339,7 +339,7 @@ class BiRNN:
             if "persist_ws" not in buf:
                 buf["persist_ws"] = ops.rnn_persist_ws(B, H, 2, x3d.device)
             ops.rnn_seq_fwd_persist(buf["seq"], buf["persist_ws"], getattr(self.store, "err_flag", None))
-        elif PERSISTENT_RNN and WIDE_SWEEP and not rdrop and ops.rnn_sweep_wide_supported(rt, B, T, H, 2) and \
+        elif PERSISTENT_RNN and WIDE_SWEEP and not rdrop and ops.device_exclusive() and ops.rnn_sweep_wide_supported(rt, B, T, H, 2) and \
                 torch.cuda.get_device_properties(x3d.device).multi_processor_count >= H // 4:
             if "wide_ws" not in buf:
                 buf["wide_ws"] = ops.rnn_sweep_wide_ws(B, H, 2, x3d.device)

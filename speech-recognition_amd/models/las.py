@@ -435,7 +435,8 @@ class LAS(ModelProto):
     def _decoder_sweep_ok(self, ws):
         ok = getattr(ws, "_sweep_ok", None)
         if ok is None:
-            ok = ws._sweep_ok = (ws.attn_fused is None and ops.decoder_sweep_supported(self.rt, self.Ld, ws.B, ws.U, ws.T2, self.Hd, 2 * self.He)
+            ok = ws._sweep_ok = (ws.attn_fused is None and ops.device_exclusive()
+                                 and ops.decoder_sweep_supported(self.rt, self.Ld, ws.B, ws.U, ws.T2, self.Hd, 2 * self.He)
                                  and torch.cuda.get_device_properties(ws.enc.device).multi_processor_count >= 256)
         return ok
 
@@ -466,7 +467,7 @@ class LAS(ModelProto):
     def _decoder_sweep_bwd_ok(self, ws):
         ok = getattr(ws, "_sweep_bwd_ok", None)
         if ok is None:
-            ok = ws._sweep_bwd_ok = (DECODER_SWEEP and DECODER_SWEEP_BWD and ws.attn_fused is None and
+            ok = ws._sweep_bwd_ok = (DECODER_SWEEP and DECODER_SWEEP_BWD and ws.attn_fused is None and ops.device_exclusive() and
                                      ops.decoder_sweep_bwd_supported(self.rt, self.Ld, ws.B, ws.U, ws.T2, self.Hd, 2 * self.He)
                                      and torch.cuda.get_device_properties(ws.enc.device).multi_processor_count >= 256)
         return ok

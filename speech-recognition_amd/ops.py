@@ -445,6 +445,23 @@ def debug_occupy(blocks: int, threads: int, microseconds: int):
     check(lib().asr_debug_occupy(int(blocks), int(threads), int(microseconds), _stream()))
 
 
+# Whole-chip sweeps (the decoder sweeps and the wide layers' sweeps: one workgroup per compute unit, all of which wait for each
+# other) need the device to themselves: a second PROCESS running the same grids on the same GPU can hold part of the chip and
+# starve this one until the start handshake gives up ("absent workgroup", sweep_common.h) - nothing in HIP gang-schedules across
+# processes.  One process per GPU (run.train, bench.py) is exclusive by construction; TrainStep detects ranks that share a
+# device and clears this switch, and the models then keep those loops on the per-step kernels (the encoder sweeps stay: they are
+# sized to 3/4 of the chip, asr_sweep_capacity).
+_tenancy = {"exclusive": True}
+
+
+def set_device_exclusive(flag: bool):
+    _tenancy["exclusive"] = bool(flag)
+
+
+def device_exclusive() -> bool:
+    return _tenancy["exclusive"]
+
+
 def debug_stream_memory(buf: torch.Tensor, blocks: int, microseconds: int):
     """Diagnostic: `blocks` workgroups stream `buf` (f32, first half copied onto the second) for `microseconds` on the current
     stream (asr_debug_stream_memory): a memory-side co-tenant."""

@@ -17,8 +17,12 @@ from typing import Dict, Optional
 
 import torch
 
+import os
+
 from . import ops
 from . import rng as R
+
+_ROCTX = os.environ.get("ASR_ROCTX", "1") != "0"
 
 
 class GradientExchange:
@@ -32,9 +36,12 @@ class GradientExchange:
     the communication stream before and after the collective, half the bytes on the 153 GB/s xGMI links - and the sum of
     the rounded replica gradients lands back in the f32 buffer (every rank ends with the same values)."""
 
-    def __init__(self, world_size: int, group=None, compute_stream=None, wire_dtype=torch.float32):
+    def __init__(self, world_size: int, group=None, compute_stream=None, wire_dtype=torch.float32, force=False):
+        """force: run the exchange (side stream, events, wire conversion, the collective itself) even for a single rank - the
+        data-parallel code path on one GPU (bench.py --dp-path, tests/test_dp_gpu.py); needs an initialised process group."""
         self.world, self.group, self.stream = world_size, group, compute_stream
-        self.comm_stream = torch.cuda.Stream() if (compute_stream is not None and world_size > 1) else None
+        self.active = world_size > 1 or bool(force)
+        self.comm_stream = torch.cuda.Stream() if (compute_stream is not None and self.active) else None
         self.wire_dtype = wire_dtype
         self._wire = {}                                   # bucket address -> bf16 staging buffer
         self._pending = []
@@ -61,7 +68,7 @@ class GradientExchange:
 
     def reduce_async(self, bucket: torch.Tensor):
         """Start summing `bucket` (a contiguous 1-D view) across ranks."""
-        if self.world <= 1 or bucket is None or bucket.numel() == 0:
+        if not self.active or bucket is None or bucket.numel() == 0:
             return
         import torch.distributed as dist
         if self.comm_stream is None:                      # CPU / gloo path
@@ -141,11 +148,13 @@ class SweepTimeout(RuntimeError):
 
 class TrainStep:
     def __init__(self, model, lr_schedule, frontend: Optional[ops.LogmelPlan] = None, strategy=None, use_graph: bool = True,
-                 beta1=0.9, beta2=0.999, eps=1e-7, eval_frontend=None):
+                 beta1=0.9, beta2=0.999, eps=1e-7, eval_frontend=None, force_dp_path: bool = False):
         """model: LAS or DeepSpeech2 (built lazily on the first batch); lr_schedule: utils.LRScheduler;
         frontend: LogmelPlan when batches arrive as raw audio, StoredFeaturePlan when they are stored
         log-mel frames, None when they are finished feature tensors; eval_frontend: the same without
-        SpecAugment, used by evaluate()."""
+        SpecAugment, used by evaluate().  force_dp_path: take the data-parallel step (one captured graph per gradient bucket's
+        backward segment, bucket all-reduces on the communication stream between them, bf16 wire under mixed precision) even
+        with a single rank - what a replica of an N-GPU job executes, measurable and checkable on one GPU."""
         self.model, self.frontend, self.strategy = model, frontend, strategy
         self.eval_frontend = eval_frontend
         self.sched_host = lr_schedule
@@ -158,13 +167,36 @@ class TrainStep:
         self.max_shapes = 16                       # input shapes kept alive (workspace + captured graphs each), least recently used evicted
         self.stream = torch.cuda.Stream()          # graphs cannot capture the legacy default stream
         # --mixed-precision (BASELINE configs[4], las_large): gradients cross the fabric as bf16
-        wire = torch.bfloat16 if (ops.mixed_precision() and self.world > 1) else torch.float32
-        self.exchange = GradientExchange(self.world, self.group, self.stream, wire_dtype=wire)
-        model.bucket_sync = self.world > 1           # per-bucket completion of side-stream work only when buckets are exchanged
+        self.segmented = self.world > 1 or bool(force_dp_path)
+        wire = torch.bfloat16 if (ops.mixed_precision() and self.segmented) else torch.float32
+        self.exchange = GradientExchange(self.world, self.group, self.stream, wire_dtype=wire, force=force_dp_path)
+        model.bucket_sync = self.segmented           # per-bucket completion of side-stream work only when buckets are exchanged
+        if self.world > 1:
+            self._detect_shared_device()
         self.iterations = 0
         self._replicas_synced = False
         if getattr(model, "built", False):
             self.sync_replicas()
+
+    def _detect_shared_device(self):
+        """Ranks that share one GPU (a test arrangement; run.train and bench.py bind one process per GPU) cannot both run whole-chip
+        sweeps: see ops.set_device_exclusive.  Every rank learns every rank's (host, device) and all of them take the same decision."""
+        import socket
+
+        import torch.distributed as dist
+        dev = torch.device(getattr(self.model, "device", None) or "cuda")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        try:
+            ident = str(torch.cuda.get_device_properties(idx).uuid)
+        except Exception:
+            ident = f"cuda:{idx}"
+        mine = (socket.gethostname(), ident)
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        shared = len(set(everyone)) < len(everyone)
+        self.shared_device = shared
+        if shared:
+            ops.set_device_exclusive(False)
 
     def sync_replicas(self):
         """Broadcast rank 0's model state to every replica (see training.sync_replicas); called once the model is built, and
@@ -230,13 +262,25 @@ class TrainStep:
         pass is one segment (one captured graph instead of one per bucket)."""
         segs = [lambda: self._fwd_loss(c, teacher)]
         bsegs = self.model.backward_segments(c["ws"], c["feats"])
-        if self.world > 1:
+        if self.segmented:
             segs += bsegs
         else:
             segs.append(lambda: [fn() for fn in bsegs])
         return segs
 
     def _run_segment(self, c, teacher, k, fn):
+        # roctx range per segment (torch.cuda.nvtx is roctx on ROCm): rocprofv3 --marker-trace shows "asr:seg<k>" around the launches /
+        # graph replays of each stage of the step (SURVEY 5: tracing)
+        if _ROCTX:
+            torch.cuda.nvtx.range_push(f"asr:seg{k}" if k != "update" else "asr:update")
+            try:
+                self._run_segment_inner(c, teacher, k, fn)
+            finally:
+                torch.cuda.nvtx.range_pop()
+        else:
+            self._run_segment_inner(c, teacher, k, fn)
+
+    def _run_segment_inner(self, c, teacher, k, fn):
         if not self.use_graph:
             fn()
             return
@@ -271,8 +315,8 @@ class TrainStep:
             c["tokens"].copy_(tokens, non_blocking=True)
             m.set_targets(c["ws"], c["tokens"], c["labels"])   # layout copies of the token rows (not captured)
             segs = self._segments(c, teacher)
-            buckets = m.store.bucket_views() if self.world > 1 else []
-            assert self.world == 1 or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
+            buckets = m.store.bucket_views() if self.segmented else []
+            assert not self.segmented or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
             # buckets complete when backward segment k ends (a model that runs a stage's weight gradients beside the next stage's sweep
             # completes them one segment late: bucket_schedule)
             done = m.bucket_schedule() if hasattr(m, "bucket_schedule") else [[k] for k in range(len(buckets))]

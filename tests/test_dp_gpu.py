@@ -46,9 +46,11 @@ def _worker(rank, world, port, q):
     # Two ranks SHARE the one GPU here (a test arrangement: real data parallelism is one process per GPU).  The decoder sweeps are
     # whole-chip launches - 256 workgroups, one per compute unit, that wait for each other - and two of them from two processes can
     # each hold part of the chip and starve the other until the start handshake gives up ("absent workgroup", sweep_common.h; seen
-    # once in ~10 runs of this test).  The per-step decoder kernels run here; the encoder sweeps (<= 3/4 of the chip, two fit side by
-    # side) stay on.  The decoder sweeps under co-tenancy are covered in-process: test_trainstep_gpu.py (foreign kernel holding CUs).
-    os.environ["ASR_DECODER_SWEEP"] = "0"
+    # once in ~10 runs of this test in round 3, which then switched them off by environment variable).  Round 4: TrainStep itself
+    # detects ranks that share a device (all-gather of host + device uuid) and keeps the whole-chip loops on the per-step kernels
+    # (ops.set_device_exclusive) - asserted below; the encoder sweeps (<= 3/4 of the chip, two fit side by side) stay on.  The
+    # decoder sweeps under co-tenancy are covered in-process: test_trainstep_gpu.py (foreign kernel holding CUs).
+    os.environ.pop("ASR_DECODER_SWEEP", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import speech_recognition_amd  # noqa: F401
@@ -61,6 +63,10 @@ def _worker(rank, world, port, q):
         own = model.store.flat.cpu().numpy().copy()
         trainer = TrainStep(model, LRScheduler(100, 1e-2, 1e-4), frontend=None, strategy=DeviceStrategy(torch.device("cuda", 0), world, rank),
                             use_graph=True)                       # ... and TrainStep replaces them with rank 0's
+        from speech_recognition_amd import ops
+        from speech_recognition_amd.models import las as las_mod
+        assert las_mod.DECODER_SWEEP and las_mod.DECODER_SWEEP_BWD, "no environment override: the product decides"
+        assert trainer.shared_device and not ops.device_exclusive(), "two ranks on one GPU must be detected"
         assert len(model.store.bucket_ranges) == 2 + CFG["num_encoder_layers"]
         params, grads, losses, persistent = [model.store.flat.cpu().numpy().copy()], [], [], []
         for s in range(STEPS):
@@ -70,6 +76,7 @@ def _worker(rank, world, port, q):
             grads.append(model.store.grad.cpu().numpy().copy())   # the all-reduced gradient the update used
             params.append(model.store.flat.cpu().numpy().copy())
             persistent.append(all("persist_ws" in lw["rnn"] and "persist_bwd_ws" in lw["rnn"] for lw in ws.layers))
+            assert not getattr(ws, "_sweep_ok", False) and not getattr(ws, "_sweep_bwd_ok", False), "whole-chip sweeps on a shared device"
         q.put((rank, own, params, grads, losses, persistent, model.state.cpu().numpy().copy()))   # by value (no fd passing)
     except BaseException:                                        # surface the failure at once instead of letting the parent wait
         import traceback
@@ -144,3 +151,77 @@ def test_two_rank_training_equals_manual_replica_mean():
         ops.advance_state(ref.state)
         torch.cuda.synchronize()
         assert np.array_equal(ref.store.flat.cpu().numpy(), p0[s + 1]), f"step {s}: parameters are not Adam(previous, reduced gradient)"
+
+
+def _dp_path_worker(port, q):
+    """A process of its own: a single-rank RCCL group ("nccl", world size 1) must not leak into the other tests' process."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import speech_recognition_amd  # noqa: F401
+        from speech_recognition_amd import ops
+        from speech_recognition_amd.training import TrainStep
+        from speech_recognition_amd.utils import DeviceStrategy, LRScheduler
+        out = {}
+        for mixed in (False, True):
+            ops.set_mixed_precision(mixed)
+            runs = {}
+            for name, force in (("single", False), ("dp", True), ("single_again", False)):
+                model = _model(seed=21)
+                trainer = TrainStep(model, LRScheduler(100, 1e-2, 1e-4), frontend=None, strategy=DeviceStrategy(torch.device("cuda", 0), 1, 0),
+                                    use_graph=True, force_dp_path=force)
+                assert trainer.segmented == force and trainer.exchange.active == force
+                if force:
+                    assert trainer.exchange.wire_dtype == (torch.bfloat16 if mixed else torch.float32)
+                losses = []
+                for s in range(4):                                 # eager, capture, replay, replay
+                    f, n, t = _batch(0, s)
+                    ws = trainer.step(f.cuda(), n.cuda(), t.cuda(), use_teacher_forcing=True)
+                    losses.append(trainer.read_stats(ws)[0])
+                c = next(iter(trainer._shapes.values()))
+                runs[name] = dict(flat=model.store.flat.cpu().numpy().copy(), losses=losses, graphs=len(c["graphs"]),
+                                  sweeps=bool(getattr(ws, "_sweep_ok", False) and getattr(ws, "_sweep_bwd_ok", False)))
+            out[mixed] = runs
+        ops.set_mixed_precision(False)
+        q.put(("ok", out))
+    except BaseException:
+        import traceback
+        q.put(("error", traceback.format_exc()))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_code_path_on_one_gpu_with_a_single_rank_rccl_group():
+    """what a replica of an N-GPU job executes - one captured graph per gradient bucket's backward segment, the
+    bucket all-reduces issued through torch.distributed "nccl" (= RCCL) on the communication stream between them, events both ways,
+    bf16 wire format under mixed precision - on one GPU with a world-size-1 RCCL group (TrainStep(force_dp_path=True)).  After four
+    steps (eager, capture, two replays) the parameters equal the single-graph step's: f32 wire to the run-to-run noise of the
+    atomically accumulated weight gradients (1e-5 of the largest parameter; two runs of the SAME path differ by as much), bf16 wire to
+    the rounding of the gradients (2^-8 relative per bucket entry, through Adam: 2e-2 of the largest parameter change)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_path_worker, args=(29700 + (os.getpid() % 1500), q))
+    p.start()
+    r = q.get(timeout=240)
+    p.join(60)
+    if r[0] == "error":
+        pytest.fail(r[1])
+    for mixed, runs in r[1].items():
+        single, dp, again = runs["single"], runs["dp"], runs["single_again"]
+        assert single["graphs"] == 3 and dp["graphs"] == 2 + (2 + CFG["num_encoder_layers"]), (single["graphs"], dp["graphs"])
+        assert single["sweeps"] and dp["sweeps"], "one rank owns its GPU: the decoder sweeps stay on in the data-parallel path"
+        scale = np.abs(single["flat"]).max()
+        noise = np.abs(single["flat"] - again["flat"]).max() / scale
+        diff = np.abs(single["flat"] - dp["flat"]).max() / scale
+        print(f"mixed={mixed}: dp path vs single graph {diff:.2e} (same path twice {noise:.2e})")
+        if not mixed:
+            assert diff <= max(1e-5, 10 * noise), (diff, noise)
+            assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
+        else:
+            assert diff <= 2e-2, diff                             # lr 1e-2 x 4 steps of sign-like Adam updates, gradients rounded to bf16 on the wire
+            assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(single["losses"], dp["losses"]))

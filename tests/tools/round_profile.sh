@@ -3,7 +3,7 @@
 # Writes gpurun_out/<round>_*.{csv,txt}; copy the ones to be judged into profiles/.
 R=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out && \
-B="--no-cpu-baseline --no-kernel-rooflines --no-extra-workloads" && \
+B="--no-cpu-baseline --no-kernel-rooflines --no-extra-workloads --no-dp-path" && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_small -o small -- python3 bench.py --steps 20 --warmup 5 $B > gpurun_out/prof_small.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ds -o ds -- python3 bench.py --workload deepspeech --steps 20 --warmup 5 $B > gpurun_out/prof_ds.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_largebf -o large -- python3 bench.py --workload las_large --steps 5 --warmup 3 $B > gpurun_out/prof_large.log 2>&1 && \
