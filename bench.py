@@ -438,6 +438,11 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default=None,
                     help="default: f32 for las_small / deepspeech (the headline dtype), bf16 mixed precision for las_large (BASELINE configs[4])")
     args = ap.parse_args()
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to file descriptor 1 when its first communicator
+    # comes up (and libraries may do likewise), so everything but the final print is sent to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     wl = WORKLOADS[args.workload]
     precision = args.precision or wl.get("precision", "f32")
 
@@ -627,7 +632,8 @@ def main():
             except Exception as e:
                 out["extra_workloads"].append({"workload": wname, "error": str(e)})
         _ops.set_mixed_precision(precision == "bf16")
-    print(json.dumps(out))
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
 
 
 if __name__ == "__main__":

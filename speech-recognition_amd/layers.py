@@ -102,23 +102,41 @@ class Overlap:
     races of the BPTT sweep that only other kernels' interference exposed (rnn_sweep_bwd.hip: ds out of place, re-arm three steps late)."""
 
     enabled = os.environ.get("ASR_OVERLAP", "0") == "1"
+    # Round 4, the arrangement that does pay: off-critical-path products run on the side stream BESIDE THE OTHER DENSE WORK of their
+    # stage (the input-gradient products, batch norm backward, the next projection's input gradient) and are joined BEFORE the next
+    # sweep starts, so a sweep always has the chip to itself.  Two streams of short-K products fill each other's prologues, C writes
+    # and ragged last rounds (each launch alone keeps the matrix pipes 40-53 % busy).  ASR_CONCURRENT=0 switches it off.
+    concurrent = os.environ.get("ASR_CONCURRENT", "1") != "0"
 
     def __init__(self, site="overlap"):
-        self.side = SideStream(site, default_on=Overlap.enabled)
+        self.mode = "beside" if Overlap.enabled else ("concurrent" if Overlap.concurrent else "off")
+        self.side = SideStream(site, default_on=self.mode != "off")
         self.pending = []
 
     @property
     def on(self):
         return self.side.on
 
+    @property
+    def late_buckets(self):
+        """True when a stage's weight gradients complete one backward segment late (released beside the NEXT stage's sweep)."""
+        return self.side.on and self.mode == "beside"
+
     def defer(self, fn):
-        if self.side.on:
-            self.pending.append(fn)
-        else:
+        if not self.side.on:
             fn()
+        elif self.mode == "concurrent":
+            self.side.run(fn)                  # now, on the side stream, beside whatever the caller enqueues next on the main stream
+        else:
+            self.pending.append(fn)
 
     def beside(self, launch, gate):
-        """Run `launch()` (a sweep) on the current stream and release the pending work next to it."""
+        """Run `launch()` (a sweep) on the current stream and release the pending work next to it ("beside" mode); in "concurrent"
+        mode the sweep first waits for the side stream: it runs alone."""
+        if self.mode == "concurrent":
+            self.side.join()
+            launch()
+            return
         if not self.pending:
             launch()
             return
@@ -208,6 +226,8 @@ def cell_input_grad(rnn_type, H, ds2d, W, dx2d, accumulate=False, c_scale=None, 
 class BiRNN:
     """BiRNN of las.py:62-126 on the step kernels: forward + backward LSTM/GRU/SimpleRNN over
     x [B,T,Din] with a frame mask, chained initial states and Keras input dropout."""
+
+    fwd_side = None          # SideStream shared by all layers (set below the class): direction 1's input projection beside direction 0's
 
     def __init__(self, store, prefix, rnn_type, Din, H, dropout, stream_in, device="cuda", recurrent_dropout=0.0, stream_rec=None):
         ops.rnn_type_id(rnn_type)
@@ -313,9 +333,16 @@ class BiRNN:
                     ops.gemm(x2d, W[:, g * H:(g + 1) * H], pre2[:, g * H:(g + 1) * H], bias=bin_[g * H:(g + 1) * H],
                              a_scale=dd["mtab_g"][g] if drop else None, a_rpg=T)
             else:
-                if drop and not tables_ready:
-                    ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
-                ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=bin_, a_scale=dd["mtab"] if drop else None, a_rpg=T)
+                def project(dd=dd, W=W, bin_=bin_, d=d):
+                    if drop and not tables_ready:
+                        ops.dropout_table(dd["mtab"], seed, self.stream_in + d, self.dropout)
+                    ops.gemm(x2d, W, dd["pre"].view(B * T, -1), bias=bin_, a_scale=dd["mtab"] if drop else None, a_rpg=T)
+                # the two directions' input projections are independent products of the same x: side by side on two streams
+                # (joined in front of the sweep below) they fill each other's prologue and last round
+                if d == 1 and Overlap.concurrent and BiRNN.fwd_side.on:
+                    BiRNN.fwd_side.run(project)
+                else:
+                    project()
             dd["bias_rec"] = b[1] if rt == "gru" else None
             dd["U"] = p[self.names[d] + "recurrent_kernel"]
             if init_states is not None:
@@ -324,6 +351,7 @@ class BiRNN:
                 dd["c0"] = st[1] if rt == "lstm" else None
             else:
                 dd["h0"] = dd["c0"] = None
+        BiRNN.fwd_side.join()
         buf["mask"] = mask
         buf["x3d"] = x3d
         buf["drop"] = drop
@@ -482,3 +510,6 @@ class BiRNN:
                 cell_input_grad(rt, H, dd[dskey].view(B * T, -1), p[self.names[d] + "kernel"], dx3d.view(B * T, self.Din),
                                 accumulate=(dx_accumulate or d == 1), c_scale=mt, c_rpg=T)
         return [dd["dh0"] for dd in buf["dirs"]]
+
+
+BiRNN.fwd_side = SideStream("fwd", default_on=Overlap.concurrent)

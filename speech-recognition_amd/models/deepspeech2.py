@@ -243,7 +243,7 @@ class DeepSpeech2(ModelProto):
         """Per backward segment, the gradient buckets complete when it ends: a recurrent layer's weight gradients run beside the
         next layer's sweep (layers.Overlap), one segment late; the last two buckets complete together."""
         n = self.Lr + 1
-        if not self._ov.on or n < 3:
+        if not self._ov.late_buckets or n < 3:
             return [[k] for k in range(n)]
         return [[0], []] + [[k - 1] for k in range(2, n - 1)] + [[n - 2, n - 1]]
 

@@ -585,7 +585,7 @@ class LAS(ModelProto):
         """Per backward segment, the gradient buckets that are complete when it ends.  With the overlap scheduler a stage's weight
         gradients run beside the NEXT stage's sweep, so every bucket completes one segment later and the last two together."""
         n = 2 + self.Le
-        if self._ov.on:
+        if self._ov.late_buckets:
             return [[]] + [[k] for k in range(n - 2)] + [[n - 2, n - 1]]
         # The vocabulary bucket (complete after segment 0) is held back until the decoder segment has been enqueued: the decoder's
         # backward sweep is one workgroup per compute unit at the register limit - an RCCL kernel that is resident when it starts keeps
