@@ -406,6 +406,7 @@ def dp_path_measure(wl, steps, use_graph, audio_d, n_d, toks_d, single_ms):
             return dt, flat, info
 
         check_steps = 3
+        os.environ["ASR_NATIVE_COLLECTIVE"] = "0"
         dt_dp, flat_dp_long, info = run(True, steps, True)
         _, flat_a, _ = run(False, check_steps, False)
         _, flat_b, _ = run(True, check_steps, False)
@@ -416,6 +417,18 @@ def dp_path_measure(wl, steps, use_graph, audio_d, n_d, toks_d, single_ms):
                "gradient_buckets": info["buckets"], "wire_dtype": info["wire"], "collective": "torch.distributed nccl (RCCL), world size 1",
                "param_rel_diff_vs_single_graph": float((flat_a - flat_b).abs().max()) / scale,
                "same_path_rel_diff": float((flat_a - flat_c).abs().max()) / scale, "check_steps": 3 + check_steps}
+        # the same step with the collectives issued by the C ABI (asr_allreduce_bucket) and captured, with the backward segments, in ONE graph
+        try:
+            os.environ["ASR_NATIVE_COLLECTIVE"] = "1"
+            dt_nat, _, info_n = run(True, steps, True)
+            _, flat_n, _ = run(True, check_steps, False)
+            out["native_collective"] = {"ms_per_step": round(dt_nat * 1e3, 3), "overhead_frac": round(dt_nat * 1e3 / single_ms - 1.0, 4),
+                                        "captured_graphs_per_step": info_n["graphs"], "collective": "asr_allreduce_bucket (RCCL called by libasr_mi355x.so), world size 1",
+                                        "param_rel_diff_vs_single_graph": float((flat_a - flat_n).abs().max()) / scale}
+        except Exception as e:
+            out["native_collective"] = {"error": str(e)}
+        finally:
+            os.environ["ASR_NATIVE_COLLECTIVE"] = "0"
         return out
     finally:
         if created:

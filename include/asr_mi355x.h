@@ -153,6 +153,7 @@ int asr_colsum(const float* A, int M, int N, long lda, float* out, void* stream)
  * (rows_per_batch 0 = one batch), so that the shifted [B, T-1, H] views of the recurrent-kernel gradient flatten into one product. */
 int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const void* B16, float* C, void* stream);
 int asr_debug_sweep_trace(unsigned long long* out, int n);   /* timing aid: stage stamps of one BPTT-sweep workgroup (ASR_SWEEP_DBG bit 128), 8 per step */
+int asr_debug_decoder_trace(unsigned long long* out, int n); /* timing aid: stage stamps of two forward decoder-sweep workgroups (ASR_DECODER_SWEEP_TRACE=1), [2][128 steps][16] */
 int asr_gemm_bf16_config(int cfg);   /* tile configuration of asr_gemm_bf16_nt (tuning and tests; -1 = query); returns the previous one */
 int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, int cols, int rows_per_batch, long batch_stride, const float* scale,
                           int rows_per_group, int transpose, void* dst, long ld_dst, int dst_rows_per_batch, int dst_shift, void* stream);
@@ -581,6 +582,24 @@ int asr_beam_select(const float* lp, const int32_t* tok, int B, int beam, int cu
 int asr_ctc_log_softmax(const float* logits, long ld, long R, int V, int blank, float* out, void* stream);
 int asr_ctc_beam_search(const float* log_probs, int B, int T, int C, const int32_t* seq_len, int beam_width, int top_paths,
                         int32_t* tokens, int32_t* lengths, float* log_prob, int threads);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (replaces the implicit all-reduce of tf.distribute.MirroredStrategy that
+ * utils.py:142-153 sets up and model.fit drives, run/train.py:203-217): RCCL over xGMI, one process per GPU.
+ *   asr_comm_available  - 1 when librccl.so.1 can be resolved in this process (it is bound at run time).
+ *   asr_comm_unique_id  - rank 0 fills 128 bytes (ncclUniqueId); the host side hands them to every rank.
+ *   asr_comm_init       - collective over all ranks: this process becomes `rank` of `nranks` (its current HIP device).
+ *   asr_allreduce_bucket- bucket[0,n) <- sum over ranks, in place, asynchronously on `stream` (capturable into a hipGraph);
+ *                         wire_bf16 = NULL: f32 on the wire; else n bf16 of device staging: the values cross the fabric as bf16
+ *                         (--mixed-precision, run/train.py:62-66) and the sum lands back in the f32 bucket.
+ *   Replicas scale their loss gradient by 1 / nranks, so SUM yields the replica mean ([TF-sem] SUM_OVER_BATCH_SIZE under
+ *   MirroredStrategy).
+ * ------------------------------------------------------------------------------------------ */
+int asr_comm_available(void);
+int asr_comm_unique_id(void* id128);
+int asr_comm_init(const void* id128, int nranks, int rank, void** comm);
+int asr_comm_destroy(void* comm);
+int asr_allreduce_bucket(void* comm, float* bucket, long n, void* wire_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side input decoding (no GPU work, thread-safe, re-entrant): what tensorflow-io does for

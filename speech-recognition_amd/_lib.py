@@ -150,6 +150,12 @@ SIGNATURES = {
     "asr_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P]),
     "asr_gemm_bf16_config": (C.c_int, [C.c_int]),
     "asr_debug_sweep_trace": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "asr_debug_decoder_trace": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "asr_comm_available": (C.c_int, []),
+    "asr_comm_unique_id": (C.c_int, [_P]),
+    "asr_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "asr_comm_destroy": (C.c_int, [_P]),
+    "asr_allreduce_bucket": (C.c_int, [_P, _P, c_long, _P, _P]),
     "asr_f32_to_bf16_image": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, c_long, _P, C.c_int, C.c_int, _P, c_long, C.c_int, C.c_int, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),

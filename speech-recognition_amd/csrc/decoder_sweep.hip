@@ -53,10 +53,24 @@ struct DsArgs {
 // LONG: the general instance - chunks of more than DS_MAXTC frames (T' > 256: streamed-frame code) and / or a batch that runs in
 // passes (row stride != rows of this launch, row offset != 0).  The kernel sits at the 256-register limit: the common instance
 // (T' <= 256, B <= 32: the benchmark's) must not pay for the general paths in spills, so they are compiled only into LONG
-template <bool LONG>
+// Stage timeline (timing aid, ASR_DECODER_SWEEP_TRACE=1; read back with asr_debug_decoder_trace, tests/tools/decoder_trace.py): s_memrealtime stamps
+// (10 ns ticks) of two workgroups - block 0 (attention chunk (0, 0) + a layer-0 cell) and block 128 (attention chunk (16, 0) + a layer-1
+// cell) - 16 per step: gather wave 0: 0 step entered, 1 h1 gathered (+ the layer-0 state product), 2 chunk scores visible, 3 partial
+// context handed to the publish wave, 4 the row's partials gathered, 5 slice combined, 6 cell operands gathered, 7 partial sums in LDS;
+// publish wave: 8 partial published, 9 slice published, 10 cell state published, 11 saved tensors stored.  Compiled into an
+// instance of its own (TRACE): the production kernel sits at the 256-register limit and must not carry the stamps.
+#define DSF_TRACE_STEPS 128
+__device__ unsigned long long dsf_trace[2 * DSF_TRACE_STEPS * 16];
+#define DS_STAMP(k)                                                                                             \
+  do {                                                                                                          \
+    if (TRACE && twg >= 0 && lane == 0 && i < DSF_TRACE_STEPS) dsf_trace[(twg * DSF_TRACE_STEPS + i) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
+template <bool LONG, bool TRACE = false>
 __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int twg = !TRACE ? -1 : ((blockIdx.x == 0 && (wv == 0 || wv == 4)) ? 0 : ((blockIdx.x == 128 && (wv == 0 || wv == 4)) ? 1 : -1));
   const bool pub_wave = wv == 4;
   const int li = lane & 15, lq = lane >> 4;
   const int w = blockIdx.x;
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
     // ================================================================================================= GATHER waves
     for (int i = 0; i < U; ++i) {
       const long slot_prev = (long)((i + 3) & 3) * a.slot_floats, slot_cur = (long)(i & 3) * a.slot_floats;
+      DS_STAMP(0);
       // ---- (1) h1 of the previous step: the attention row (every wave keeps its own LDS copy) and, for layer-0 cells, the tile ----
       f32x4 hv[5];
       f32x4 acc_h = {0.f, 0.f, 0.f, 0.f};
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           }
         }
       }
+      DS_STAMP(1);
       // ---- (2) scores of the chunk, chunk-local softmax, partial context ----
       if (attn) {
         // thread (t = tid / 8, kg = tid % 8): partial dot over the k's congruent to kg (float4 granularity)
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         }
         ds_mark(cE, wave, i + 1);
         if (!ds_wait4(cE, i + 1, abort_flag, lds_limit, 5 | (i << 8))) break;
+        DS_STAMP(2);
         // every lane evaluates the chunk's softmax statistics itself from broadcast LDS reads of the <= 32 scores (no cross-lane
         // traffic: a chain of ten dependent wave shuffles costs more than 32 hardware exponentials); lanes 0-31 of every wave leave
         // the weights in the wave's own LDS copy, from where the context loop reads them as broadcasts
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         if (tid == 0) { pbuf[0] = m; pbuf[1] = l; pbuf[2] = 0.f; pbuf[3] = 0.f; }
       }
       ds_mark(cA, wave, i + 1);
+      DS_STAMP(3);
       // ---- (3) the row's 8 partials: statistics + this workgroup's feature slice; combine.  A layer-0 cell's previous cell state
       //          (c1 of the previous step, its own block) rides in the same gather ----
       {
@@ -314,6 +332,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           *reinterpret_cast<f32x4*>(cblk + lane * 4) = cvv;
         }
       }
+      DS_STAMP(4);
       if (attn) {
         ds_mark(cB, wave, i + 1);
         if (wave == 0) {
@@ -337,6 +356,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           if (lane == 0) *cC = i + 1;
         }
       }
+      DS_STAMP(5);
       // ---- (4) the cell of this workgroup's layer ----
       if (cell) {
         f32x4 acc0 = acc_h, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -366,6 +386,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
             }
           }
           if (!ds_gather8(cx, o8, use, cv, abort_flag, a.spin_limit, a.delay, 3 | (i << 8))) break;
+          DS_STAMP(6);
 #pragma unroll
           for (int k = 0; k < 8; ++k)
             if (!use[k]) cv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -407,6 +428,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
             }
           }
           if (!ds_gather5(hx, o5, use, hv, abort_flag, a.spin_limit, a.delay, 4 | (i << 8))) break;
+          DS_STAMP(6);
           if (wave == 0 && lane < 16) *reinterpret_cast<f32x4*>(cblk + lane * 4) = hv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k)                            // (static register indices: a run-time pick would go through scratch)
@@ -433,6 +455,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         for (int r = 0; r < 4; ++r) ptw[(lq * 4 + r) * 17 + li] = acc[r];
       }
       ds_mark(cD, wave, i + 1);
+      DS_STAMP(7);
     }
   } else {
     // ================================================================================================= PUBLISH wave
@@ -475,6 +498,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + base + 4 * pc) * 4), 0, 16);
         }
       }
+      DS_STAMP(8);
       // ---- the combined context slice ----
       if (attn) {
         if (!ds_wait(cC, i + 1, abort_flag, lds_limit, 8 | (i << 8))) break;
@@ -488,6 +512,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
         if (lane < FS) a.ctx[((long)i * Bs_ + ab) * D + FS * ac + lane] = cslice[lane];
         if (lane < nt) a.p[((long)i * Bs_ + ab) * T2 + t_lo + lane] = pn[lane];
       }
+      DS_STAMP(9);
       // ---- the cell ----
       if (!ds_wait4(cD, i + 1, abort_flag, lds_limit, 9 | (i << 8))) break;
       if (cell) {
@@ -513,6 +538,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + oh + blk) * 4), 0, 16);
           __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)((slot_old + oc + blk) * 4), 0, 16);
         }
+        DS_STAMP(10);
         if (live) {
           const long row = (long)i * Bs_ + brow;
           float* svp = (layer == 0 ? a.saved0 : a.saved1) + row * 4 * Hd + j;
@@ -528,6 +554,7 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
           }
         }
       }
+      DS_STAMP(11);
     }
   }
   __syncthreads();
@@ -566,11 +593,11 @@ extern "C" int asr_decoder_sweep_supported(int rnn_type, int num_layers, int B, 
   // the spin limit reports it - sweep_common.h says which); a device that cannot hold the grid even when empty is refused here
   static long cap = 0;
   if (cap == 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, cus = 0, per = 0;
     cap = -1;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), 320, ds_lds_bytes(256, 512)) == hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false, false>), 320, ds_lds_bytes(256, 512)) == hipSuccess)
       cap = (long)per * cus;
     (void)hipGetLastError();
   }
@@ -616,8 +643,8 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
   const size_t smem = ds_lds_bytes(s->Hd, s->D);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // one launch per 32 batch rows (the grid is 32 rows x 8 chunks of attention and 2 batch tiles of cells): the passes are independent
@@ -637,9 +664,19 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
                        reinterpret_cast<uint32_t*>(ws), n, DS_SENT, a.err, 16, 256u);
     (void)asr_zero_async(a.err + 32, 256 * sizeof(unsigned), st);
     ASR_LAUNCH_CHECK();
-    if (a.TC > DS_MAXTC || a.Bs != a.B || a.b0 != 0) hipLaunchKernelGGL(decoder_sweep_fwd_kernel<true>, dim3(256), dim3(320), smem, st, a);
-    else hipLaunchKernelGGL(decoder_sweep_fwd_kernel<false>, dim3(256), dim3(320), smem, st, a);
+    static const int trace = getenv("ASR_DECODER_SWEEP_TRACE") ? atoi(getenv("ASR_DECODER_SWEEP_TRACE")) : 0;
+    if (a.TC > DS_MAXTC || a.Bs != a.B || a.b0 != 0) hipLaunchKernelGGL((decoder_sweep_fwd_kernel<true, false>), dim3(256), dim3(320), smem, st, a);
+    else if (trace) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((decoder_sweep_fwd_kernel<false, true>), dim3(256), dim3(320), smem, st, a);
+    } else hipLaunchKernelGGL((decoder_sweep_fwd_kernel<false, false>), dim3(256), dim3(320), smem, st, a);
     ASR_LAUNCH_CHECK();
   }
   return ASR_OK;
+}
+
+// Timing aid: the stage stamps of the last traced forward decoder sweep (ASR_DECODER_SWEEP_TRACE=1): n <= 2 * 128 * 16 words.
+extern "C" int asr_debug_decoder_trace(unsigned long long* out, int n) {
+  if (!out || n <= 0 || n > 2 * DSF_TRACE_STEPS * 16) return ASR_ERR_ARG;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dsf_trace), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? ASR_OK : ASR_ERR_HIP;
 }

@@ -25,6 +25,48 @@ from . import rng as R
 _ROCTX = os.environ.get("ASR_ROCTX", "1") != "0"
 
 
+class NativeComm:
+    """An RCCL communicator owned by libasr_mi355x.so (asr_comm_init): the collective entry point of the C ABI
+    (asr_allreduce_bucket) issues straight into RCCL on a HIP stream, so the bucket all-reduces can be captured into the same
+    hipGraph as the backward segments around them.  The 128-byte unique id travels through torch.distributed's process group
+    (any backend); with one rank nothing travels."""
+
+    def __init__(self, world: int, rank: int, group=None):
+        import ctypes as C
+
+        from . import _lib
+        self.lib = _lib.load()
+        if not self.lib.asr_comm_available():
+            raise RuntimeError("librccl.so.1 cannot be resolved in this process")
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(self.lib.asr_comm_unique_id(buf))
+        ident = bytes(buf.raw)
+        if world > 1:
+            import torch.distributed as dist
+            box = [ident]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = box[0]
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.asr_comm_init(ident, int(world), int(rank), C.byref(self.handle)))
+        self.world, self.rank = world, rank
+
+    def all_reduce(self, bucket: torch.Tensor, wire: Optional[torch.Tensor] = None):
+        """In-place SUM of the f32 `bucket` over the ranks, on the current stream; wire: bf16 staging of the same length or None."""
+        import ctypes as C
+
+        from . import _lib
+        assert bucket.dtype == torch.float32 and bucket.is_contiguous() and bucket.is_cuda
+        _lib.check(self.lib.asr_allreduce_bucket(self.handle, C.c_void_p(bucket.data_ptr()), bucket.numel(),
+                                                 C.c_void_p(wire.data_ptr()) if wire is not None else None,
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def close(self):
+        if self.handle:
+            self.lib.asr_comm_destroy(self.handle)
+            self.handle = None
+
+
 class GradientExchange:
     """Data-parallel gradient exchange (the implicit all-reduce of tf.distribute.MirroredStrategy,
     utils.py:148-149): sums the buckets of a flat gradient buffer across the ranks of a process group.
@@ -36,10 +78,13 @@ class GradientExchange:
     the communication stream before and after the collective, half the bytes on the 153 GB/s xGMI links - and the sum of
     the rounded replica gradients lands back in the f32 buffer (every rank ends with the same values)."""
 
-    def __init__(self, world_size: int, group=None, compute_stream=None, wire_dtype=torch.float32, force=False):
+    def __init__(self, world_size: int, group=None, compute_stream=None, wire_dtype=torch.float32, force=False, native: Optional["NativeComm"] = None):
         """force: run the exchange (side stream, events, wire conversion, the collective itself) even for a single rank - the
-        data-parallel code path on one GPU (bench.py --dp-path, tests/test_dp_gpu.py); needs an initialised process group."""
+        data-parallel code path on one GPU (bench.py --dp-path, tests/test_dp_gpu.py); needs an initialised process group.
+        native: a NativeComm - the collective is then the C ABI's asr_allreduce_bucket (RCCL called from the library, capturable)
+        instead of torch.distributed's all_reduce."""
         self.world, self.group, self.stream = world_size, group, compute_stream
+        self.native = native
         self.active = world_size > 1 or bool(force)
         self.comm_stream = torch.cuda.Stream() if (compute_stream is not None and self.active) else None
         self.wire_dtype = wire_dtype
@@ -53,6 +98,9 @@ class GradientExchange:
         return self._wire[key]
 
     def _all_reduce(self, bucket, dist):
+        if self.native is not None and bucket.is_cuda:
+            self.native.all_reduce(bucket, self._staging(bucket) if self.wire_dtype == torch.bfloat16 else None)
+            return
         if self.wire_dtype != torch.bfloat16:
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             return
@@ -169,7 +217,15 @@ class TrainStep:
         # --mixed-precision (BASELINE configs[4], las_large): gradients cross the fabric as bf16
         self.segmented = self.world > 1 or bool(force_dp_path)
         wire = torch.bfloat16 if (ops.mixed_precision() and self.segmented) else torch.float32
-        self.exchange = GradientExchange(self.world, self.group, self.stream, wire_dtype=wire, force=force_dp_path)
+        # ASR_NATIVE_COLLECTIVE=1: the bucket all-reduces go through the C ABI (asr_allreduce_bucket: RCCL called by the library on the
+        # communication stream) and, being capturable, the whole data-parallel step becomes ONE hipGraph (forward, every backward
+        # segment, the collectives forked beside them) instead of one graph per segment with host-side collectives in between.
+        # Default off until a multi-GPU node has run it: the torch.distributed route is the one the N > 1 CPU / GPU tests cover.
+        native = None
+        if self.segmented and os.environ.get("ASR_NATIVE_COLLECTIVE", "0") == "1":
+            native = NativeComm(self.world, strategy.rank if strategy is not None else 0, self.group)
+        self.exchange = GradientExchange(self.world, self.group, self.stream, wire_dtype=wire, force=force_dp_path, native=native)
+        self.one_graph = native is not None
         model.bucket_sync = self.segmented           # per-bucket completion of side-stream work only when buckets are exchanged
         if self.world > 1:
             self._detect_shared_device()
@@ -262,7 +318,20 @@ class TrainStep:
         pass is one segment (one captured graph instead of one per bucket)."""
         segs = [lambda: self._fwd_loss(c, teacher)]
         bsegs = self.model.backward_segments(c["ws"], c["feats"])
-        if self.segmented:
+        if self.segmented and self.one_graph:
+            # native collectives: one callable = one captured graph; the bucket all-reduces are enqueued (forked onto the communication
+            # stream) at the points of the backward pass where their buckets complete, and joined before the update
+            def whole():
+                m = self.model
+                buckets = m.store.bucket_views()
+                done = m.bucket_schedule() if hasattr(m, "bucket_schedule") else [[k] for k in range(len(buckets))]
+                for k, fn in enumerate(bsegs):
+                    fn()
+                    for b in done[k]:
+                        self.exchange.reduce_async(buckets[b])
+                self.exchange.wait()
+            segs.append(whole)
+        elif self.segmented:
             segs += bsegs
         else:
             segs.append(lambda: [fn() for fn in bsegs])
@@ -315,8 +384,8 @@ class TrainStep:
             c["tokens"].copy_(tokens, non_blocking=True)
             m.set_targets(c["ws"], c["tokens"], c["labels"])   # layout copies of the token rows (not captured)
             segs = self._segments(c, teacher)
-            buckets = m.store.bucket_views() if self.segmented else []
-            assert not self.segmented or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
+            buckets = m.store.bucket_views() if (self.segmented and not self.one_graph) else []
+            assert not buckets or len(buckets) == len(segs) - 1, "one gradient bucket per backward segment"
             # buckets complete when backward segment k ends (a model that runs a stage's weight gradients beside the next stage's sweep
             # completes them one segment late: bucket_schedule)
             done = m.bucket_schedule() if hasattr(m, "bucket_schedule") else [[k] for k in range(len(buckets))]

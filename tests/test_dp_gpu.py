@@ -168,11 +168,14 @@ def _dp_path_worker(port, q):
         for mixed in (False, True):
             ops.set_mixed_precision(mixed)
             runs = {}
-            for name, force in (("single", False), ("dp", True), ("single_again", False)):
+            for name, force in (("single", False), ("dp", True), ("single_again", False), ("dp_native", True)):
+                # dp_native: the collective through the C ABI (asr_allreduce_bucket -> RCCL), the whole data-parallel step ONE graph
+                os.environ["ASR_NATIVE_COLLECTIVE"] = "1" if name == "dp_native" else "0"
                 model = _model(seed=21)
                 trainer = TrainStep(model, LRScheduler(100, 1e-2, 1e-4), frontend=None, strategy=DeviceStrategy(torch.device("cuda", 0), 1, 0),
                                     use_graph=True, force_dp_path=force)
                 assert trainer.segmented == force and trainer.exchange.active == force
+                assert (trainer.exchange.native is not None) == (name == "dp_native")
                 if force:
                     assert trainer.exchange.wire_dtype == (torch.bfloat16 if mixed else torch.float32)
                 losses = []
@@ -185,6 +188,7 @@ def _dp_path_worker(port, q):
                                   sweeps=bool(getattr(ws, "_sweep_ok", False) and getattr(ws, "_sweep_bwd_ok", False)))
             out[mixed] = runs
         ops.set_mixed_precision(False)
+        os.environ["ASR_NATIVE_COLLECTIVE"] = "0"
         q.put(("ok", out))
     except BaseException:
         import traceback
@@ -212,16 +216,19 @@ def test_data_parallel_code_path_on_one_gpu_with_a_single_rank_rccl_group():
     if r[0] == "error":
         pytest.fail(r[1])
     for mixed, runs in r[1].items():
-        single, dp, again = runs["single"], runs["dp"], runs["single_again"]
-        assert single["graphs"] == 3 and dp["graphs"] == 2 + (2 + CFG["num_encoder_layers"]), (single["graphs"], dp["graphs"])
-        assert single["sweeps"] and dp["sweeps"], "one rank owns its GPU: the decoder sweeps stay on in the data-parallel path"
+        single, again = runs["single"], runs["single_again"]
+        assert single["graphs"] == 3 and runs["dp"]["graphs"] == 2 + (2 + CFG["num_encoder_layers"]), (single["graphs"], runs["dp"]["graphs"])
+        assert runs["dp_native"]["graphs"] == 3, "native collectives: forward, backward with the collectives inside, update"
         scale = np.abs(single["flat"]).max()
         noise = np.abs(single["flat"] - again["flat"]).max() / scale
-        diff = np.abs(single["flat"] - dp["flat"]).max() / scale
-        print(f"mixed={mixed}: dp path vs single graph {diff:.2e} (same path twice {noise:.2e})")
-        if not mixed:
-            assert diff <= max(1e-5, 10 * noise), (diff, noise)
-            assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
-        else:
-            assert diff <= 2e-2, diff                             # lr 1e-2 x 4 steps of sign-like Adam updates, gradients rounded to bf16 on the wire
-            assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
+        for name in ("dp", "dp_native"):
+            dp = runs[name]
+            assert single["sweeps"] and dp["sweeps"], "one rank owns its GPU: the decoder sweeps stay on in the data-parallel path"
+            diff = np.abs(single["flat"] - dp["flat"]).max() / scale
+            print(f"mixed={mixed}: {name} vs single graph {diff:.2e} (same path twice {noise:.2e})")
+            if not mixed:
+                assert diff <= max(1e-5, 10 * noise), (name, diff, noise)
+                assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
+            else:
+                assert diff <= 2e-2, (name, diff)                 # lr 1e-2 x 4 steps of sign-like Adam updates, gradients rounded to bf16 on the wire
+                assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
