@@ -115,7 +115,11 @@ typedef struct asr_gemm_desc {
   int c_rpg;
   int compute;                 /* 0: f32 operands on the f32 MFMA (exact products); 1: mixed precision (train.py:62-66
                                   --mixed-precision): operands rounded to bf16 (RNE) into the bf16 MFMA, f32
-                                  accumulation, f32 storage and epilogue                                       */
+                                  accumulation, f32 storage and epilogue; 2: f32 operands, every product a * b evaluated
+                                  as the nine bf16 pair products of the exact three-way splits a = a1 + a2 + a3,
+                                  b = b1 + b2 + b3 on the bf16 MFMA (2^-32 relative per product: tighter than an f32
+                                  FMA), f32 accumulation - the f32 arithmetic of the reference at ~2x the f32-MFMA
+                                  rate; 3: the same without the three pairs of weight <= 2^-24 (<= 3 * 2^-24 |a b|) */
 } asr_gemm_desc;
 int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
 

@@ -1,8 +1,10 @@
 // asr_gemm_f32: general f32 GEMM on the f32-input MFMA (see gemm_core.h); desc.compute = 1 rounds the operands to
 // bf16 on their way into the bf16 MFMA (f32 storage, accumulation and epilogue: the mixed-precision mode).
 //
-// This file is compiled twice (the kernels dominate the library's build time): as gemm.hip with GEMM_BF = 0 (the f32
-// kernels and the C entry point) and through gemm_bf16.hip with GEMM_BF = 1 (the bf16-operand kernels).
+// This file is compiled four times (the kernels dominate the library's build time): as gemm.hip with GEMM_BF = 0 (the f32-MFMA
+// kernels and the C entry point), through gemm_bf16.hip with GEMM_BF = 1 (the bf16-operand kernels of --mixed-precision) and
+// through gemm_split9.hip / gemm_split6.hip with GEMM_BF = 2 / 3 (f32 products as nine / six exact bf16 pair products on the
+// bf16 matrix pipe: gemm_core.h run_split).
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -28,8 +30,9 @@ template <class AL, class BL, int TA, int TB, int BM, int BN, int WAVES_M, int W
 __global__ __launch_bounds__(256) void gemm_kernel(AL al, BL bl, GemmEpilogue ep, int K, long sAz, long sBz, long sCz, long sAscale,
                                                    int tiles_m, int tiles_n, int walk_n, int split_k, int k_chunk) {
   using T = GemmTile<TA, TB, BM, BN, WAVES_M, WAVES_N>;
-  __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
+  constexpr int LBF = BF >= 2 ? 2 : BF;                        // LDS image: f32 tiles (0, 1) or three bf16 planes (2, 3)
+  __shared__ __attribute__((aligned(16))) float As[T::template a_lds<LBF>()];
+  __shared__ __attribute__((aligned(16))) float Bs[T::template b_lds<LBF>()];
   const int z = blockIdx.z / split_k, zs = blockIdx.z % split_k;
   al.offset_z((long)z * sAz, (long)z * sAscale);
   bl.offset_z((long)z * sBz, 0);
@@ -39,7 +42,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(AL al, BL bl, GemmEpilogue ep
   if (kbeg >= K && !(K == 0 && zs == 0)) return;
   int bm, bn;
   tile_of_block(tiles_m, tiles_n, walk_n, &bm, &bn);
-  T::template run<BF>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  if constexpr (BF == 2) T::template run_split<9>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  else if constexpr (BF == 3) T::template run_split<6>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  else T::template run<BF>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 struct GemmPlan {
@@ -115,10 +120,16 @@ static inline bool aligned16(const void* p, long ld, long stride) {
   return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0) && (stride % 4 == 0);
 }
 
-#if GEMM_BF
+#if GEMM_BF == 1
 int asr_gemm_launch_bf16(const GemmPlan& g) {
+#elif GEMM_BF == 2
+int asr_gemm_launch_split9(const GemmPlan& g) {
+#elif GEMM_BF == 3
+int asr_gemm_launch_split6(const GemmPlan& g) {
 #else
 int asr_gemm_launch_bf16(const GemmPlan& g);
+int asr_gemm_launch_split9(const GemmPlan& g);
+int asr_gemm_launch_split6(const GemmPlan& g);
 static int asr_gemm_launch_f32(const GemmPlan& g) {
 #endif
   const asr_gemm_desc* d = g.d;
@@ -157,7 +168,8 @@ extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float*
             "asr_gemm_f32: leading dimension smaller than row length (lda %ld ldb %ld ldc %ld)", d->lda, d->ldb, d->ldc);
   ASR_CHECK((long)d->batch * (d->split_k > 1 ? d->split_k : 1) <= 65535, ASR_ERR_SHAPE, "asr_gemm_f32: batch*split_k > 65535");
   ASR_CHECK(!(d->split_k > 1 && !d->accumulate), ASR_ERR_ARG, "asr_gemm_f32: split_k > 1 accumulates atomically: set accumulate and pre-zero C");
-  ASR_CHECK(d->compute == 0 || d->compute == 1, ASR_ERR_ARG, "asr_gemm_f32: compute must be 0 (f32) or 1 (bf16 operands), got %d", d->compute);
+  ASR_CHECK(d->compute >= 0 && d->compute <= 3, ASR_ERR_ARG,
+            "asr_gemm_f32: compute must be 0 (f32 MFMA), 1 (bf16 operands), 2 (f32 as nine bf16 pair products) or 3 (six), got %d", d->compute);
   ASR_CHECK(!(d->a_scale && d->a_rpg <= 0) && !(d->c_scale && d->c_rpg <= 0), ASR_ERR_ARG,
             "asr_gemm_f32: group scale needs rows-per-group > 0");
   int mode = d->accumulate ? 1 : 0;
@@ -168,6 +180,9 @@ extern "C" int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float*
   if (d->accumulate == 2 || d->split_k > 1) mode = 2;
   g.ep = GemmEpilogue{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
 
-  return d->compute == 1 ? asr_gemm_launch_bf16(g) : asr_gemm_launch_f32(g);
+  if (d->compute == 1) return asr_gemm_launch_bf16(g);
+  if (d->compute == 2) return asr_gemm_launch_split9(g);
+  if (d->compute == 3) return asr_gemm_launch_split6(g);
+  return asr_gemm_launch_f32(g);
 }
 #endif

@@ -171,9 +171,180 @@ struct GemmTile {
   static constexpr int B_ELEMS = BN * BK;
   static constexpr int A_V4 = BM * BK / 4 / 256;  // float4 fetches per thread per tile
   static constexpr int B_V4 = BN * BK / 4 / 256;
+  // LDS floats per operand by arithmetic mode: BF 0 / 1 keep the f32 tile; BF 2 (three-way bf16 split, below) keeps three bf16 planes
+  template <int BF> static constexpr int a_lds() { return BF == 2 ? BM * 48 : A_ELEMS; }     // 3 planes x 32 k x 2 B = 192 B = 48 floats per row
+  template <int BF> static constexpr int b_lds() { return BF == 2 ? BN * 48 : B_ELEMS; }
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(A_V4 >= 1 && B_V4 >= 1, "tile too small for 256 threads");
   static_assert(256 % (BM / 4) == 0 && 256 % (BN / 4) == 0 && 256 % (BK / 4) == 0, "per-thread fixed fetch column");
+
+  // ------------------------------------------------------------------------------------------------------------------
+  // BF = 2: f32 products on the bf16 matrix pipe.  gfx950 multiplies f32 on the matrix cores at 1/16 of its bf16 rate
+  // (MI355X_MICROARCH.md), so an f32 product is evaluated as a sum of bf16 x bf16 products instead: every operand element is split
+  // EXACTLY into three bf16 values x = x1 + x2 + x3 (8 + 8 + 8 significant bits, by truncation: each remainder is exactly
+  // representable), once per element as the tile goes to LDS, and a * b = sum over the nine pairs a_i * b_j, each pair an exact
+  // product inside v_mfma_f32_32x32x16_bf16 (f32 accumulation).  TERMS = 9 reproduces every bit of every product a * b (2^-32
+  // relative) - more than an f32 FMA chain keeps; TERMS = 6 drops the three pairs of weight <= 2^-24 (a2 b3, a3 b2, a3 b3: error
+  // <= 3 * 2^-24 |a b| per product, the size of one f32 rounding).  Accumulation is f32 in both, as in the f32 MFMA.  Cost per
+  // 32 x 32 x 16 block: 9 (6) bf16 MFMAs of 8 passes against 8 f32 MFMAs of 16 passes.  Inf / NaN operands give NaN (inf - inf
+  // in the split); finite values, zeros and denormals are exact.
+  // LDS image: per operand three planes [mn][32 k] of bf16 (64-byte rows), the four 16-byte chunks of a row XOR-swizzled with
+  // (mn >> 2) & 3 - a lane's MFMA operand (8 consecutive k) is ONE ds_read_b128 and the reads are conflict-free.
+  static __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));          // <= 8 significant bits: the low half of the pattern is zero
+  }
+  static __device__ __forceinline__ unsigned pack2(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | (hi_elem & 0xFFFF0000u); }
+
+  // store V4 float4 fetches of a k-contiguous operand: fetch i covers row (tid + 256 i) / 8, k = 4 ((tid + 256 i) % 8) .. + 3
+  template <int V4, int BMN>
+  static __device__ __forceinline__ void split_store_kc(const float (&r)[V4][4], char* base, int tid) {
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      const int f = tid + i * 256, row = f >> 3, q = f & 7;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(r[i][e], h[e], m[e], l[e]);
+      const int off = row * 64 + ((((q >> 1) ^ ((row >> 2) & 3)) << 4) | ((q & 1) << 3));
+      *reinterpret_cast<uint2*>(base + off) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+      *reinterpret_cast<uint2*>(base + BMN * 64 + off) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
+      *reinterpret_cast<uint2*>(base + 2 * BMN * 64 + off) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+    }
+  }
+  // store V4 float4 fetches of an mn-contiguous operand: the thread holds k = kb .. kb + V4 - 1 (kb = V4 (tid / (BMN / 4))) of the four
+  // rows mn = 4 (tid % (BMN / 4)) .. + 3: V4 consecutive k of one row are V4 bf16 = one 2 / 4 / 8 / 16-byte LDS store per plane
+  template <int V4, int BMN>
+  static __device__ __forceinline__ void split_store_mc(const float (&r)[V4][4], char* base, int tid) {
+    const int kb = V4 * (tid / (BMN / 4)), mn0 = 4 * (tid % (BMN / 4));
+    unsigned h[V4][4], m[V4][4], l[V4][4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(r[i][e], h[i][e], m[i][e], l[i][e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = mn0 + e;
+      char* dst = base + row * 64 + ((((kb >> 3) ^ ((row >> 2) & 3)) << 4) | ((kb & 7) << 1));
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        char* d = dst + pl * BMN * 64;
+        auto v = [&](int i) { return pl == 0 ? h[i][e] : (pl == 1 ? m[i][e] : l[i][e]); };
+        if constexpr (V4 == 1) *reinterpret_cast<unsigned short*>(d) = (unsigned short)(v(0) >> 16);
+        else if constexpr (V4 == 2) *reinterpret_cast<unsigned*>(d) = pack2(v(0), v(1));
+        else if constexpr (V4 == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pack2(v(0), v(1)), pack2(v(2), v(3)));
+        else *reinterpret_cast<uint4*>(d) = make_uint4(pack2(v(0), v(1)), pack2(v(2), v(3)), pack2(v(4), v(5)), pack2(v(6), v(7)));
+      }
+    }
+  }
+
+  template <int TERMS, class AL, class BL>
+  static __device__ __forceinline__ void run_split(const AL& al, const BL& bl, const GemmEpilogue& ep, int kbeg, int kend,
+                                                   int m0, int n0, float* As, float* Bs) {
+    static_assert(BK == 32, "the split path stages 32-deep K tiles");
+    static_assert(A_V4 == 1 || A_V4 == 2 || A_V4 == 4 || A_V4 == 8, "fetches per thread");
+    static_assert(B_V4 == 1 || B_V4 == 2 || B_V4 == 4 || B_V4 == 8, "fetches per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    float ra[A_V4][4], rb[B_V4][4];
+    f32x16 acc[MI][NI], acs[MI][NI];                       // acs: the low-order pairs, summed apart and added once at the end
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+    char* Ab = reinterpret_cast<char*>(As);
+    char* Bb = reinterpret_cast<char*>(Bs);
+    typename AL::Row arow[A_KC ? A_V4 : 1];
+    typename BL::Row brow[B_KC ? B_V4 : 1];
+    const typename AL::Col acol = al.col(m0 + 4 * (tid % (BM / 4)));
+    const typename BL::Col bcol = bl.col(n0 + 4 * (tid % (BN / 4)));
+    if (A_KC) {
+#pragma unroll
+      for (int i = 0; i < A_V4; ++i) arow[i] = al.row(m0 + (tid + i * 256) / (BK / 4));
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int i = 0; i < B_V4; ++i) brow[i] = bl.row(n0 + (tid + i * 256) / (BK / 4));
+    }
+    auto gload = [&](int k0) {
+      if (A_KC) {
+        const typename AL::Col kc = al.col(k0 + 4 * (tid % (BK / 4)));
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) al.fetch4(arow[i], kc, ra[i]);
+      } else {                                             // (k rows A_V4 (tid / (BM / 4)) + i: consecutive k per thread, see split_store_mc)
+#pragma unroll
+        for (int i = 0; i < A_V4; ++i) al.fetch4(al.row(k0 + A_V4 * (tid / (BM / 4)) + i), acol, ra[i]);
+      }
+      if (B_KC) {
+        const typename BL::Col kc = bl.col(k0 + 4 * (tid % (BK / 4)));
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) bl.fetch4(brow[i], kc, rb[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < B_V4; ++i) bl.fetch4(bl.row(k0 + B_V4 * (tid / (BN / 4)) + i), bcol, rb[i]);
+      }
+    };
+    auto lstore = [&]() {
+      if (A_KC) split_store_kc<A_V4, BM>(ra, Ab, tid); else split_store_mc<A_V4, BM>(ra, Ab, tid);
+      if (B_KC) split_store_kc<B_V4, BN>(rb, Bb, tid); else split_store_mc<B_V4, BN>(rb, Bb, tid);
+    };
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int l31 = lane & 31, lh = lane >> 5;
+    gload(kbeg);
+    for (int kt = 0; kt < nk; ++kt) {
+      lstore();
+      __syncthreads();
+      if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {                     // two 16-deep MFMA steps per K tile: chunk 2 s2 + lh of the row
+        bf16x8 a8[3][MI], b8[3][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = wm * WM + i * 32 + l31;
+          const int off = m * 64 + ((((2 * s2 + lh) ^ ((m >> 2) & 3))) << 4);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a8[pl][i] = *reinterpret_cast<const bf16x8*>(Ab + pl * BM * 64 + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = wn * WN + j * 32 + l31;
+          const int off = n * 64 + ((((2 * s2 + lh) ^ ((n >> 2) & 3))) << 4);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b8[pl][j] = *reinterpret_cast<const bf16x8*>(Bb + pl * BN * 64 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            // pairs by weight: (1,1) 1, (1,2) (2,1) 2^-8, (1,3) (2,2) (3,1) 2^-16 | (2,3) (3,2) 2^-24, (3,3) 2^-32
+            if (TERMS == 9) {
+              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[2][j], acs[i][j], 0, 0, 0);
+              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[2][j], acs[i][j], 0, 0, 0);
+              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[1][j], acs[i][j], 0, 0, 0);
+            }
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2][j], acs[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0][j], acc[i][j], 0, 0, 0);
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1][j], acs[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1][j], acc[i][j], 0, 0, 0);
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0][j], acs[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0][j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long srow = ep.map_row(row);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ep.put(row, srow, n0 + wn * WN + j * 32 + l31, acc[i][j][r] + acs[i][j][r]);
+      }
+  }
 
   // BF = 1: the operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) as they leave LDS and the
   // products run on v_mfma_f32_32x32x16_bf16 with the same f32 accumulators - "mixed precision" with f32 storage,

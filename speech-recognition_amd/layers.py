@@ -108,9 +108,15 @@ class Overlap:
     # and ragged last rounds (each launch alone keeps the matrix pipes 40-53 % busy).  ASR_CONCURRENT=0 switches it off.
     concurrent = os.environ.get("ASR_CONCURRENT", "1") != "0"
 
+    lanes = int(os.environ.get("ASR_CONCURRENT_LANES", "1"))       # side streams the concurrent mode deals its work over
+
     def __init__(self, site="overlap"):
         self.mode = "beside" if Overlap.enabled else ("concurrent" if Overlap.concurrent else "off")
         self.side = SideStream(site, default_on=self.mode != "off")
+        # concurrent mode: independent deferred products are dealt round-robin over `lanes` side streams (a layer's two directions'
+        # weight gradients run beside each other as well as beside the main stream's input-gradient products)
+        self.more = [SideStream(site, default_on=self.side.on) for _ in range(max(0, Overlap.lanes - 1))] if self.mode == "concurrent" else []
+        self._rr = 0
         self.pending = []
 
     @property
@@ -126,7 +132,9 @@ class Overlap:
         if not self.side.on:
             fn()
         elif self.mode == "concurrent":
-            self.side.run(fn)                  # now, on the side stream, beside whatever the caller enqueues next on the main stream
+            lanes = [self.side] + self.more    # now, on a side stream, beside whatever the caller enqueues next on the main stream
+            lanes[self._rr % len(lanes)].run(fn)
+            self._rr += 1
         else:
             self.pending.append(fn)
 
@@ -134,7 +142,7 @@ class Overlap:
         """Run `launch()` (a sweep) on the current stream and release the pending work next to it ("beside" mode); in "concurrent"
         mode the sweep first waits for the side stream: it runs alone."""
         if self.mode == "concurrent":
-            self.side.join()
+            self.join_all()
             launch()
             return
         if not self.pending:
@@ -145,6 +153,12 @@ class Overlap:
         work, self.pending = self.pending, []
         self.side.run_after(ev, work, gate)
 
+    def join_all(self):
+        self.side.join()
+        for sd in self.more:
+            sd.join()
+        self._rr = 0
+
     def flush(self, join=True):
         """Release what is still pending behind everything enqueued so far (no sweep to hide behind) and, with join, make the
         current stream wait for the side stream: the end of a backward pass / of a gradient bucket's segment."""
@@ -152,7 +166,7 @@ class Overlap:
             work, self.pending = self.pending, []
             self.side.run_after(self.side.fork(), work, None)
         if join:
-            self.side.join()
+            self.join_all()
 
 
 def auto_split_k(M, N, K):
@@ -447,11 +461,13 @@ class BiRNN:
                     if rt == "gru":
                         ops.colsum(ds2[:, sl * H:(sl + 1) * H], gb[1][cb * H:(cb + 1) * H])
 
-        def param_grads():      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
+        def param_grads(only=None):      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
             if buf["rdrop"]:
                 return param_grads_per_gate()
             shared = rt == "lstm" and T > 1 and ops.bf16_images_pay(H, 4 * H, B * (T - 1)) and ops.bf16_images_pay(self.Din, 4 * H, B * T)
             for d, dd in enumerate(buf["dirs"]):
+                if only is not None and d != only:
+                    continue
                 nm = self.names[d]
                 ds3 = dd[dskey]
                 ds2 = ds3.view(B * T, -1)
@@ -491,7 +507,10 @@ class BiRNN:
                         t0 = T - 1 if dd["reverse"] else 0
                         ops.gemm(dd["h0"], ds3[:, t0, s0:s0 + n], gU, trans_a=True, accumulate=1)
 
-        if overlap is not None:
+        if overlap is not None and overlap.mode == "concurrent" and overlap.on and not buf["rdrop"]:
+            for d in range(len(buf["dirs"])):                      # the two directions' products are independent: one lane each
+                overlap.defer(lambda d=d: param_grads(d))
+        elif overlap is not None:
             overlap.defer(param_grads)
         elif side is not None:
             side.run(param_grads)

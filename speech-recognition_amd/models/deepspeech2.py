@@ -280,7 +280,7 @@ class DeepSpeech2(ModelProto):
             ws.dfin_next = l.backward(lw["rnn"], ws.dy, ws.dfin_next, ws.dc, dx, side=self._side)    # weight gradients beside this layer's dX / the next BatchNorm
         if i > 0:
             if getattr(self, "bucket_sync", False):
-                (self._ov.side if self._ov.on else self._side).join()   # data parallel: a complete bucket when the segment ends
+                (self._ov.join_all() if self._ov.on else self._side.join())   # data parallel: a complete bucket when the segment ends
             return
         self._ov.flush(join=False)         # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
@@ -292,7 +292,7 @@ class DeepSpeech2(ModelProto):
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]
-        self._ov.side.join()
+        self._ov.join_all()
         self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API

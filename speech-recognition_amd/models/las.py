@@ -609,7 +609,7 @@ class LAS(ModelProto):
         if rate > 0:
             ops.dropout_rows(ws.dyd, ws.dyd, self.seed, mk(1, Hd))
         if getattr(self, "bucket_sync", False):
-            self._ov.side.join()
+            self._ov.join_all()
 
     def backward_decoder(self, ws):
         p, g = self.store.p, self.store.g
@@ -744,7 +744,7 @@ class LAS(ModelProto):
                     ops.gemm(fin[d * nst + k], dsrc, gW[d * He:(d + 1) * He], trans_a=True, accumulate=1)
         ov.defer(state_proj_weight_grads)
         if getattr(self, "bucket_sync", False):
-            ov.side.join()
+            ov.join_all()
 
     def backward_encoder_layer(self, ws, audio, i):
         """Encoder layer i backwards (las.py:190-193): BatchNorm+ReLU, projection, BiRNN; the convolutions follow layer 0."""
@@ -767,7 +767,7 @@ class LAS(ModelProto):
         ws.dfin_next = l.backward(lw["rnn"], ws.dy, dfin, ws.dc_enc, dx, overlap=ov)   # this layer's dW / dU / db: beside the next sweep
         if i > 0:
             if getattr(self, "bucket_sync", False):
-                ov.side.join()             # data parallel: what ran beside this layer's sweep is a complete bucket when the segment ends
+                ov.join_all()             # data parallel: what ran beside this layer's sweep is a complete bucket when the segment ends
             return
         ov.flush(join=False)               # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # ---- convolutions (las.py:183-184)
@@ -781,7 +781,7 @@ class LAS(ModelProto):
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
         ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"])
-        ov.side.join()
+        ov.join_all()
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):

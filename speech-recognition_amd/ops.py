@@ -242,6 +242,23 @@ def _mat(t, name):
 
 
 _compute = {"gemm": 0}
+# How an f32 product is evaluated when mixed precision is off (asr_gemm_desc.compute): "mfma" = 0, the f32 MFMA (exact products,
+# 1/16 of the bf16 matrix rate on gfx950); "split9" = 2, every product as the nine bf16 pair products of exact three-way splits
+# of both operands on the bf16 MFMA (2^-32 relative per product - tighter than an f32 FMA chain - f32 accumulation); "split6" = 3,
+# the same without the three pairs of weight <= 2^-24.  ASR_GEMM_F32 selects it.
+_F32_MODES = {"mfma": 0, "split9": 2, "split6": 3}
+_f32_mode = {"compute": _F32_MODES[os.environ.get("ASR_GEMM_F32", "mfma")]}
+
+
+def set_f32_gemm_mode(name: str):
+    """'mfma' | 'split9' | 'split6' (see above); returns the previous name."""
+    old = next(k for k, v in _F32_MODES.items() if v == _f32_mode["compute"])
+    _f32_mode["compute"] = _F32_MODES[name]
+    return old
+
+
+def f32_gemm_mode() -> str:
+    return next(k for k, v in _F32_MODES.items() if v == _f32_mode["compute"])
 
 
 def set_mixed_precision(on: bool):
@@ -322,7 +339,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, alpha=1.0, accumulate=0, bias
     d.a_rpg = int(a_rpg)
     d.c_scale = c_scale.data_ptr() if c_scale is not None else None
     d.c_rpg = int(c_rpg)
-    d.compute = _compute["gemm"] if compute is None else int(compute)
+    d.compute = (_compute["gemm"] or _f32_mode["compute"]) if compute is None else int(compute)
     if d.compute == 1 and _bf16_images["on"] and _gemm_bf16_images(d, a, b, c, trans_a, trans_b, a_scale, a_rpg, a_scale_stride):
         return c
     check(lib().asr_gemm_f32(C.byref(d), _p(a), _p(b), _p(c), _stream()))

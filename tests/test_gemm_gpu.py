@@ -128,3 +128,52 @@ def test_gemm_bf16_scaled_operand_splitk_and_switch():
     assert_close(c, ref, 5e-6, "bf16 split-K with a_scale")
     with pytest.raises(ValueError):
         ops.gemm(A.cuda(), B.cuda(), c, trans_a=True, compute=3)
+
+
+# ---------------------------------------------------------------------------------------------- f32 products on the bf16 matrix pipe
+@pytest.mark.parametrize("compute,tol", [(2, 2e-6), (3, 2e-6)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (996, 512, 608), (33, 77, 19), (1, 1, 1), (300, 32, 27), (16, 1000, 256), (250, 130, 5),
+                                   (2048, 2048, 300), (32, 512, 100), (700, 24, 90)])
+def test_gemm_split_bf16_products_all_layouts(compute, tol, ta, tb, M, N, K):
+    """asr_gemm_desc.compute = 2 / 3: f32 operands split exactly into three bf16 parts, products as nine (six) bf16 pair products on
+    the bf16 MFMA, f32 accumulation - against the float64 product at the SAME tolerance as the f32 MFMA (2e-6 of the largest entry),
+    every layout, ragged tiles, every tile shape (64 / 128 / 256 x 32), bias + alpha epilogue."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g, dtype=torch.float64)
+    B = torch.randn((N, K) if tb else (K, N), generator=g, dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    a, b, bi = gpu(A), gpu(B), gpu(bias)
+    ref = (a.double().cpu().T if ta else a.double().cpu()) @ (b.double().cpu().T if tb else b.double().cpu()) * 0.5 + bi.double().cpu()
+    c = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(a, b, c, trans_a=bool(ta), trans_b=bool(tb), alpha=0.5, bias=bi, compute=compute)
+    assert_close(c, ref, tol, f"split gemm compute={compute} ta={ta} tb={tb} {M}x{N}x{K}")
+
+
+def test_gemm_split_is_at_least_as_accurate_as_the_f32_mfma():
+    """The nine-pair evaluation keeps every product to 2^-32 and differs from the f32 MFMA only in accumulation order: on a long
+    contraction with a wide dynamic range (operands spanning 2^+-12) its error against float64 must not exceed the f32 MFMA's by
+    more than 1.5x; the six-pair one stays within 3x.  Split-K, scaled A rows and strided views run the same kernels."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 512, 384, 4096
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-12, 13, (M, K), generator=g).float())
+    B = torch.randn(K, N, generator=g) * torch.exp2(torch.randint(-12, 13, (K, N), generator=g).float())
+    a, b = gpu(A), gpu(B)
+    ref = A.double() @ B.double()
+    errs = {}
+    for compute in (0, 2, 3):
+        c = torch.empty(M, N, device="cuda")
+        ops.gemm(a, b, c, compute=compute)
+        errs[compute] = float((c.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    print("max-normalised error vs float64: f32 MFMA %.3e, nine pairs %.3e, six pairs %.3e" % (errs[0], errs[2], errs[3]))
+    assert errs[2] <= 1.5 * errs[0] + 1e-9 and errs[3] <= 3.0 * errs[0] + 1e-9, errs
+    # row-group scale + split-K + accumulate through the split kernels
+    rpg = 64
+    asc = torch.rand(M // rpg, K, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    c = gpu(C0)
+    ops.gemm(a, b, c, accumulate=1, split_k=4, a_scale=gpu(asc), a_rpg=rpg, compute=2)
+    ref2 = C0.double() + (A.double() * asc.double().repeat_interleave(rpg, 0)) @ B.double()
+    assert_close(c, ref2, 2e-6, "split gemm with row-group scale, split-K, accumulate")
