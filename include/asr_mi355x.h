@@ -122,6 +122,10 @@ typedef struct asr_gemm_desc {
                                   rate; 3: the same without the three pairs of weight <= 2^-24 (<= 3 * 2^-24 |a b|) */
 } asr_gemm_desc;
 int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
+/* Process-wide choice of how the CONVOLUTIONS (asr_conv2d_*) evaluate their f32 products: 0 the f32 MFMA, 2 / 3 nine / six bf16 pair
+ * products of exact three-way operand splits on the bf16 MFMA (asr_gemm_desc.compute has the definitions; a GEMM carries its own
+ * choice per call).  Returns the previous mode.  Default: the environment variable ASR_GEMM_F32 = mfma | split9 | split6. */
+int asr_set_f32_product_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * Conv2D, padding VALID, NHWC activations, HWIO kernel, linear (las.py:163-164 + 183-184,

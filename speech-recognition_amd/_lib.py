@@ -151,6 +151,7 @@ SIGNATURES = {
     "asr_gemm_bf16_config": (C.c_int, [C.c_int]),
     "asr_debug_sweep_trace": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "asr_debug_decoder_trace": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "asr_set_f32_product_mode": (C.c_int, [C.c_int]),
     "asr_comm_available": (C.c_int, []),
     "asr_comm_unique_id": (C.c_int, [_P]),
     "asr_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),

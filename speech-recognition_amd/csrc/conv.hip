@@ -9,6 +9,9 @@
 // pos = (b, ho, wo); kc = (r, s, c) with c fastest - exactly the HWIO kernel's row index.
 #include <stdlib.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "gemm_core.h"
 
 struct ConvGeom {
@@ -143,25 +146,27 @@ struct WtClassLoader {
   }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC, int SP>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Im2colLoader<VEC> al, PlainLoader bl, GemmEpilogue ep, int K, int tiles_m) {
   using T = GemmTile<0, 0, BM, BN, WAVES_M, WAVES_N, BK>;
-  __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float As[T::template a_lds<(SP ? 2 : 0)>()];
+  __shared__ __attribute__((aligned(16))) float Bs[T::template b_lds<(SP ? 2 : 0)>()];
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
-  T::template run<0>(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
+  if constexpr (SP) T::template run_split<SP>(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
+  else T::template run<0>(al, bl, ep, 0, K, bm * BM, bn * BN, As, Bs);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC, int SP>
 __global__ __launch_bounds__(256) void conv_bwd_filter_kernel(Im2colLoader<VEC> al, PlainLoader bl, GemmEpilogue ep, int K,
                                                               int tiles_m, int k_chunk) {
   using T = GemmTile<1, 0, BM, BN, WAVES_M, WAVES_N, BK>;
-  __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float As[T::template a_lds<(SP ? 2 : 0)>()];
+  __shared__ __attribute__((aligned(16))) float Bs[T::template b_lds<(SP ? 2 : 0)>()];
   const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
   if (kbeg >= K) return;
   const int bm = blockIdx.x % tiles_m, bn = blockIdx.x / tiles_m;
-  T::template run<0>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  if constexpr (SP) T::template run_split<SP>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  else T::template run<0>(al, bl, ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
 
 // all stride classes of one data-gradient in ONE launch (class = blockIdx.z): their tiles fill the chip
@@ -179,11 +184,11 @@ struct ConvClassSet { ConvClass<VEC> c[CONV_MAX_CLASSES]; };
 
 // blockIdx.y = K partition (gridDim.y > 1: the partitions of a tile add up atomically into a pre-zeroed dX - few large tiles leave the
 // last round of workgroups mostly empty: deepspeech conv3 has 558 tiles of 363 K steps for 512 resident workgroups)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int VEC, int SP>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs) {
   using T = GemmTile<0, 1, BM, BN, WAVES_M, WAVES_N, BK>;
-  __shared__ __attribute__((aligned(16))) float As[T::A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float Bs[T::B_ELEMS];
+  __shared__ __attribute__((aligned(16))) float As[T::template a_lds<(SP ? 2 : 0)>()];
+  __shared__ __attribute__((aligned(16))) float Bs[T::template b_lds<(SP ? 2 : 0)>()];
   const ConvClass<VEC>& cc = cs.c[blockIdx.z];
   if ((int)blockIdx.x >= cc.tiles) return;
   DyClassLoader<VEC> al = cc.al;
@@ -210,8 +215,34 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(ConvClassSet<VEC> cs
     al.Cc = kend;
     bl.Cc = kend;
   }
-  T::template run<0>(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  if constexpr (SP) T::template run_split<SP>(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
+  else T::template run<0>(al, bl, cc.ep, kbeg, kend, bm * BM, bn * BN, As, Bs);
 }
+
+// How the convolutions evaluate their f32 products (asr_set_f32_product_mode; the same three evaluations as asr_gemm_desc.compute 0 / 2 / 3:
+// f32 MFMA, nine or six bf16 pair products of exact three-way operand splits on the bf16 MFMA - gemm_core.h run_split)
+static int g_conv_mode = -1;
+static int conv_mode() {
+  if (g_conv_mode < 0) {
+    const char* e = getenv("ASR_GEMM_F32");
+    g_conv_mode = (e && !strcmp(e, "split9")) ? 2 : ((e && !strcmp(e, "split6")) ? 3 : 0);
+  }
+  return g_conv_mode;
+}
+extern "C" int asr_set_f32_product_mode(int mode) {
+  ASR_CHECK(mode == 0 || mode == 2 || mode == 3, ASR_ERR_ARG, "asr_set_f32_product_mode: 0 (f32 MFMA), 2 (nine bf16 pair products) or 3 (six), got %d", mode);
+  const int old = conv_mode();
+  g_conv_mode = mode;
+  return old;
+}
+#define CONV_UNPACK(...) __VA_ARGS__
+#define CONV_GO(KERN, P, ...)                                                             \
+  do {                                                                                    \
+    const int mode__ = conv_mode();                                                       \
+    if (mode__ == 2) hipLaunchKernelGGL((KERN<CONV_UNPACK P, 9>), __VA_ARGS__);            \
+    else if (mode__ == 3) hipLaunchKernelGGL((KERN<CONV_UNPACK P, 6>), __VA_ARGS__);       \
+    else hipLaunchKernelGGL((KERN<CONV_UNPACK P, 0>), __VA_ARGS__);                        \
+  } while (0)
 
 static int conv_geom(const asr_conv_desc* d, ConvGeom* g) {
   ASR_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->O > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0,
@@ -254,21 +285,21 @@ extern "C" int asr_conv2d_fwd(const asr_conv_desc* d, const float* x, const floa
   static const int narrow_bm = getenv("ASR_CONV_FWD_BM") ? atoi(getenv("ASR_CONV_FWD_BM")) : 128;
   if (N <= 32 && narrow_bm == 128) {
     const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 32);
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
-    else hipLaunchKernelGGL((conv_fwd_kernel<128, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
+    if (vec) CONV_GO(conv_fwd_kernel, (128, 32, 4, 1, 32, 1), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else CONV_GO(conv_fwd_kernel, (128, 32, 4, 1, 32, 0), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
   } else if (N <= 32) {
     const int tm = asr_cdiv(M, 256), tn = asr_cdiv(N, 32);
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
-    else hipLaunchKernelGGL((conv_fwd_kernel<256, 32, 4, 1, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
+    if (vec) CONV_GO(conv_fwd_kernel, (256, 32, 4, 1, 32, 1), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else CONV_GO(conv_fwd_kernel, (256, 32, 4, 1, 32, 0), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
   } else if (vec && fwd_small) {
     // 64 x 64 tiles: deepspeech conv3 (M = 40320, N = 96) makes 630 workgroups of 128 x 64 - a full round and a 23 % one at two per CU;
     // 1260 smaller ones balance better (922 -> 840 us); one 128-wide column tile (im2col gathered once) measured 1209 us
     const int tm = asr_cdiv(M, 64), tn = asr_cdiv(N, 64);
-    hipLaunchKernelGGL((conv_fwd_kernel<64, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    CONV_GO(conv_fwd_kernel, (64, 64, 2, 2, 32, 1), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
   } else {
     const int tm = asr_cdiv(M, 128), tn = asr_cdiv(N, 64);
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, 32, 1>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
-    else hipLaunchKernelGGL((conv_fwd_kernel<128, 64, 2, 2, 32, 0>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
+    if (vec) CONV_GO(conv_fwd_kernel, (128, 64, 2, 2, 32, 1), dim3((unsigned)(tm * tn)), dim3(256), 0, st, av, bl, ep, K, tm);
+    else CONV_GO(conv_fwd_kernel, (128, 64, 2, 2, 32, 0), dim3((unsigned)(tm * tn)), dim3(256), 0, st, as, bl, ep, K, tm);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -303,16 +334,16 @@ extern "C" int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, con
   splits = asr_cdiv(K, k_chunk);
   ASR_CHECK(splits <= 65535, ASR_ERR_SHAPE, "asr_conv2d_bwd_filter: too many K partitions");
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)splits);
-  if (tiny && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else if (tiny) hipLaunchKernelGGL((conv_bwd_filter_kernel<32, 128, 1, 4, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
-  else if (narrow && vec && dw_bm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else if (narrow && dw_bm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
-  else if (narrow && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else if (narrow) hipLaunchKernelGGL((conv_bwd_filter_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
-  else if (wide && vec && wbm == 128) hipLaunchKernelGGL((conv_bwd_filter_kernel<128, 128, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else if (wide && vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 128, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else if (vec) hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
-  else hipLaunchKernelGGL((conv_bwd_filter_kernel<64, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  if (tiny && vec) CONV_GO(conv_bwd_filter_kernel, (32, 128, 1, 4, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (tiny) CONV_GO(conv_bwd_filter_kernel, (32, 128, 1, 4, 32, 0), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (narrow && vec && dw_bm == 128) CONV_GO(conv_bwd_filter_kernel, (128, 32, 4, 1, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (narrow && dw_bm == 128) CONV_GO(conv_bwd_filter_kernel, (128, 32, 4, 1, 32, 0), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (narrow && vec) CONV_GO(conv_bwd_filter_kernel, (256, 32, 4, 1, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (narrow) CONV_GO(conv_bwd_filter_kernel, (256, 32, 4, 1, 32, 0), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
+  else if (wide && vec && wbm == 128) CONV_GO(conv_bwd_filter_kernel, (128, 128, 2, 2, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (wide && vec) CONV_GO(conv_bwd_filter_kernel, (64, 128, 2, 2, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else if (vec) CONV_GO(conv_bwd_filter_kernel, (64, 64, 2, 2, 32, 1), grid, dim3(256), 0, st, av, bl, ep, K, tm, k_chunk);
+  else CONV_GO(conv_bwd_filter_kernel, (64, 64, 2, 2, 32, 0), grid, dim3(256), 0, st, as, bl, ep, K, tm, k_chunk);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -359,12 +390,12 @@ extern "C" int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, cons
   auto flush = [&]() {
     if (n == 0) return;
     dim3 grid((unsigned)max_tiles, (unsigned)splits, (unsigned)n);
-    if (narrow && o_vec && BMh == 128) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
-    else if (narrow && BMh == 128) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, ss);
-    else if (narrow && o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 1>), grid, dim3(256), 0, st, sv);
-    else if (narrow) hipLaunchKernelGGL((conv_bwd_data_kernel<256, 32, 4, 1, 32, 0>), grid, dim3(256), 0, st, ss);
-    else if (o_vec) hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 1>), grid, dim3(256), 0, st, sv);
-    else hipLaunchKernelGGL((conv_bwd_data_kernel<128, 64, 2, 2, 32, 0>), grid, dim3(256), 0, st, ss);
+    if (narrow && o_vec && BMh == 128) CONV_GO(conv_bwd_data_kernel, (128, 32, 4, 1, 32, 1), grid, dim3(256), 0, st, sv);
+    else if (narrow && BMh == 128) CONV_GO(conv_bwd_data_kernel, (128, 32, 4, 1, 32, 0), grid, dim3(256), 0, st, ss);
+    else if (narrow && o_vec) CONV_GO(conv_bwd_data_kernel, (256, 32, 4, 1, 32, 1), grid, dim3(256), 0, st, sv);
+    else if (narrow) CONV_GO(conv_bwd_data_kernel, (256, 32, 4, 1, 32, 0), grid, dim3(256), 0, st, ss);
+    else if (o_vec) CONV_GO(conv_bwd_data_kernel, (128, 64, 2, 2, 32, 1), grid, dim3(256), 0, st, sv);
+    else CONV_GO(conv_bwd_data_kernel, (128, 64, 2, 2, 32, 0), grid, dim3(256), 0, st, ss);
     n = 0; max_tiles = 0;
   };
   for (int ph = 0; ph < g.sh; ++ph)

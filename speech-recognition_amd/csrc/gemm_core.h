@@ -196,7 +196,8 @@ struct GemmTile {
     m = __float_as_uint(r1) & 0xFFFF0000u;
     l = __float_as_uint(r1 - __uint_as_float(m));          // <= 8 significant bits: the low half of the pattern is zero
   }
-  static __device__ __forceinline__ unsigned pack2(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | (hi_elem & 0xFFFF0000u); }
+  // the upper halves of two f32 patterns as one dword (v_perm_b32: bytes 2, 3 of each)
+  static __device__ __forceinline__ unsigned pack2(unsigned lo_elem, unsigned hi_elem) { return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u); }
 
   // store V4 float4 fetches of a k-contiguous operand: fetch i covers row (tid + 256 i) / 8, k = 4 ((tid + 256 i) % 8) .. + 3
   template <int V4, int BMN>
@@ -248,13 +249,18 @@ struct GemmTile {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     float ra[A_V4][4], rb[B_V4][4];
-    f32x16 acc[MI][NI], acs[MI][NI];                       // acs: the low-order pairs, summed apart and added once at the end
+    // a wave with ONE output tile (64 x 64 workgroup tile) has no independent MFMA to put between two dependent ones: its two 16-deep
+    // steps of a K tile then accumulate into two accumulators (16 more registers), added at the end
+    constexpr bool DUAL = MI * NI == 1;
+    f32x16 acc[MI][NI], acc2[1][1];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[0][0][r] = 0.f;
     char* Ab = reinterpret_cast<char*>(As);
     char* Bb = reinterpret_cast<char*>(Bs);
     typename AL::Row arow[A_KC ? A_V4 : 1];
@@ -320,17 +326,21 @@ struct GemmTile {
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
             // pairs by weight: (1,1) 1, (1,2) (2,1) 2^-8, (1,3) (2,2) (3,1) 2^-16 | (2,3) (3,2) 2^-24, (3,3) 2^-32
+            // (one accumulator: a second one for the low-order pairs would double the accumulator registers and cost the 128 x 128
+            // tile its occupancy; the pairs go in by rising weight inside each 16-deep block instead)
+            f32x16 c = (DUAL && s2 == 1) ? acc2[0][0] : acc[i][j];
             if (TERMS == 9) {
-              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[2][j], acs[i][j], 0, 0, 0);
-              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[2][j], acs[i][j], 0, 0, 0);
-              acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[1][j], acs[i][j], 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[1][j], c, 0, 0, 0);
             }
-            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2][j], acs[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0][j], acc[i][j], 0, 0, 0);
-            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1][j], acs[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1][j], acc[i][j], 0, 0, 0);
-            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0][j], acs[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0][j], acc[i][j], 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[2][i], b8[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[1][i], b8[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[0][i], b8[0][j], c, 0, 0, 0);
+            if (DUAL && s2 == 1) acc2[0][0] = c; else acc[i][j] = c;
           }
       }
       __syncthreads();
@@ -342,7 +352,7 @@ struct GemmTile {
         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const long srow = ep.map_row(row);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) ep.put(row, srow, n0 + wn * WN + j * 32 + l31, acc[i][j][r] + acs[i][j][r]);
+        for (int j = 0; j < NI; ++j) ep.put(row, srow, n0 + wn * WN + j * 32 + l31, DUAL ? acc[i][j][r] + acc2[0][0][r] : acc[i][j][r]);
       }
   }
 

@@ -127,7 +127,7 @@ def test_gemm_bf16_scaled_operand_splitk_and_switch():
         ops.set_mixed_precision(False)
     assert_close(c, ref, 5e-6, "bf16 split-K with a_scale")
     with pytest.raises(ValueError):
-        ops.gemm(A.cuda(), B.cuda(), c, trans_a=True, compute=3)
+        ops.gemm(A.cuda(), B.cuda(), c, trans_a=True, compute=7)
 
 
 # ---------------------------------------------------------------------------------------------- f32 products on the bf16 matrix pipe

@@ -35,8 +35,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["mfma", "split9", "split6"])
+def f32_product_mode(request):
+    """Every evaluation of an f32 product the library offers (asr_gemm_desc.compute 0 / 2 / 3, asr_set_f32_product_mode): the f32 MFMA
+    and the nine / six bf16 pair products of exact three-way operand splits - all held to the SAME tolerances against float64."""
+    ops = _ops()
+    old = ops.set_f32_gemm_mode(request.param)
+    yield request.param
+    ops.set_f32_gemm_mode(old)
+
+
 @pytest.mark.parametrize("xs,ws,st", CONV_CASES)
-def test_conv2d_forward_and_gradients(xs, ws, st):
+def test_conv2d_forward_and_gradients(xs, ws, st, f32_product_mode):
     ops = _ops()
     g = torch.Generator().manual_seed(sum(xs) + sum(ws))
     x = torch.randn(xs, generator=g, dtype=torch.float64, requires_grad=True)
