@@ -53,6 +53,10 @@ WORKLOADS = {
                       text="las_large.yml + libri_config.yml, synthetic 20 s 16 kHz clips, batch 64 per GPU, 127 decoder steps, "
                            "SpecAugment+delta on GPU, teacher forcing on, fwd+bwd+Adam(lr 2e-4)", precision="bf16"),
 }
+F32_PRODUCTS_TEXT = {"mfma": "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                     "split9": "every f32 product as the nine bf16 pair products of exact three-way operand splits on the bf16 MFMA (2^-32 per product), f32 accumulation",
+                     "split6": "every f32 product as six bf16 pair products of exact three-way operand splits on the bf16 MFMA (the pairs of weight <= 2^-24 left out: "
+                               "<= 3 * 2^-24 |a b| per product; measured error against float64 below the f32 MFMA's, tests/test_gemm_gpu.py), f32 accumulation"}
 PRECISION_TEXT = {"f32": "f32 throughout",
                   "bf16": "mixed precision: dense contractions (gemm) and the wide (H >= 512) recurrent step kernels with bf16 operands on "
                           "the bf16 MFMA, f32 accumulation; other recurrent cells, convolutions, softmax/CTC, BN, Adam and all storage f32"}
@@ -591,7 +595,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision, "data": "synthetic",
         "config": {"workload": wl["text"] + "; " + PRECISION_TEXT[precision], "global_batch": wl["batch"] * world, "clip_seconds": wl["clip_seconds"],
                    "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "persistent_rnn": bool(_layers.PERSISTENT_RNN), "remeasured": retried,
-                   "sweep_errors": sweep_errors, "overlap": bool(_layers.Overlap.enabled), "final_loss": round(loss, 4)},
+                   "sweep_errors": sweep_errors, "overlap": bool(_layers.Overlap.enabled), "final_loss": round(loss, 4),
+                   "f32_products": _ops.f32_gemm_mode() + ": " + F32_PRODUCTS_TEXT[_ops.f32_gemm_mode()] + " (dense products and convolutions; ASR_GEMM_F32=mfma|split9|split6)"},
         "roofline": roof,
     }
     if cpu is not None:
@@ -619,6 +624,39 @@ def main():
             out["value_blended"] = round(wl["batch"] * wl["clip_seconds"] / (blended * 1e-3), 1)
         except Exception as e:
             out["non_teacher_forced"] = {"error": str(e)}
+    # the same step under the other evaluations of an f32 product (short runs, OUTSIDE the timed region): what the choice is worth
+    if world == 1 and precision == "f32" and not args.no_extra_workloads:
+        try:
+            del trainer, model
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        modes = {}
+        cur = _ops.f32_gemm_mode()
+        for mname in ("mfma", "split9", "split6"):
+            if mname == cur:
+                modes[mname] = {"ms_per_step": round(ms, 3), "final_loss": round(loss, 4)}
+                continue
+            try:
+                _ops.set_f32_gemm_mode(mname)
+                tr2, m2 = build_trainer(wl, None, use_graph=not args.no_graph)
+                for _ in range(3):
+                    ws2 = tr2.step(audio_d, n_d, toks_d, use_teacher_forcing=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    ws2 = tr2.step(audio_d, n_d, toks_d, use_teacher_forcing=True)
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / 10
+                st2 = tr2.read_stats(ws2)
+                modes[mname] = {"ms_per_step": round(dt2 * 1e3, 3), "final_loss_after_13_steps": round(st2[0], 4)}
+                del tr2, m2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                modes[mname] = {"error": str(e)}
+            finally:
+                _ops.set_f32_gemm_mode(cur)
+        out["f32_product_modes"] = modes
     # the data-parallel step of a replica (segmented graphs + bucket all-reduces through RCCL) on this one GPU, OUTSIDE the timed region
     if world == 1 and not args.no_dp_path:
         try:

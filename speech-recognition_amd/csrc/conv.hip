@@ -225,7 +225,7 @@ static int g_conv_mode = -1;
 static int conv_mode() {
   if (g_conv_mode < 0) {
     const char* e = getenv("ASR_GEMM_F32");
-    g_conv_mode = (e && !strcmp(e, "split9")) ? 2 : ((e && !strcmp(e, "split6")) ? 3 : 0);
+    g_conv_mode = (e && !strcmp(e, "split9")) ? 2 : ((e && !strcmp(e, "mfma")) ? 0 : 3);      // default: six pairs (ops.py has the same default)
   }
   return g_conv_mode;
 }

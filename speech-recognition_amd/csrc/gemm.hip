@@ -99,8 +99,15 @@ static void launch_t(const GemmPlan& g, const AL& al, const BL& bl) {
   const int sk1 = d->split_k > 1 ? d->split_k : 1;
   const int k_iters = asr_cdiv(asr_cdiv(d->K, sk1), GEMM_BK);
   static const double e64s = getenv("ASR_GEMM_E64") ? atof(getenv("ASR_GEMM_E64")) : 1.02;
-  const double e64 = k_iters <= 32 ? e64s : 0.80, e128x64 = k_iters <= 32 ? 0.97 : 0.92;
-  const double s128 = score(128, 128, 1.0), s12864 = score(128, 64, e128x64), s64128 = score(64, 128, e128x64), s64 = score(64, 64, e64);
+  double e128 = 1.0, e64 = k_iters <= 32 ? e64s : 0.80, e128x64 = k_iters <= 32 ? 0.97 : 0.92, e64x128 = e128x64;
+  if (GEMM_BF >= 2) {
+    // the split evaluation has 2.7x less matrix time per K tile to hide the same staging behind: a K tile costs LDS traffic rather than
+    // MFMA issue, and a wave that owns two output tiles reads 3/4 of the fragments per MFMA that a one-tile wave reads.  Measured on
+    // the step's shapes (tests/tools/bench_gemm_modes.py with ASR_GEMM_TILE = 1..4): 128 x 64 wins the short-K products (encoder
+    // input projection 75 -> 66 us, vocabulary projection 147 -> 131), 128 x 128 the long contractions, 64 x 64 only the small ones
+    e128 = k_iters <= 32 ? 0.97 : 1.0; e128x64 = 1.0; e64x128 = 0.97; e64 = 0.90;
+  }
+  const double s128 = score(128, 128, e128), s12864 = score(128, 64, e128x64), s64128 = score(64, 128, e64x128), s64 = score(64, 64, e64);
   if (s128 >= s12864 && s128 >= s64128 && s128 >= s64) launch_cfg<AL, BL, TA, TB, 128, 128, 2, 2>(g, al, bl);
   else if (s12864 >= s64128 && s12864 >= s64) launch_cfg<AL, BL, TA, TB, 128, 64, 2, 2>(g, al, bl);
   else if (s64128 >= s64) launch_cfg<AL, BL, TA, TB, 64, 128, 2, 2>(g, al, bl);

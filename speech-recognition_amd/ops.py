@@ -247,7 +247,7 @@ _compute = {"gemm": 0}
 # of both operands on the bf16 MFMA (2^-32 relative per product - tighter than an f32 FMA chain - f32 accumulation); "split6" = 3,
 # the same without the three pairs of weight <= 2^-24.  ASR_GEMM_F32 selects it.
 _F32_MODES = {"mfma": 0, "split9": 2, "split6": 3}
-_f32_mode = {"compute": _F32_MODES[os.environ.get("ASR_GEMM_F32", "mfma")]}
+_f32_mode = {"compute": _F32_MODES[os.environ.get("ASR_GEMM_F32", "split6")]}
 
 
 def set_f32_gemm_mode(name: str):

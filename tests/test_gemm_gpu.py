@@ -168,7 +168,18 @@ def test_gemm_split_is_at_least_as_accurate_as_the_f32_mfma():
         ops.gemm(a, b, c, compute=compute)
         errs[compute] = float((c.double().cpu() - ref).abs().max()) / float(ref.abs().max())
     print("max-normalised error vs float64: f32 MFMA %.3e, nine pairs %.3e, six pairs %.3e" % (errs[0], errs[2], errs[3]))
-    assert errs[2] <= 1.5 * errs[0] + 1e-9 and errs[3] <= 3.0 * errs[0] + 1e-9, errs
+    assert errs[2] <= 1.25 * errs[0] + 1e-9 and errs[3] <= 1.25 * errs[0] + 1e-9, errs       # (measured: 1.42e-6 / 8.6e-7 / 8.6e-7)
+    # ... and on the training step's own shapes with N(0, 1) operands: root-mean-square error of each evaluation against float64
+    for (M2, N2, K2) in ((1024, 512, 512), (256, 384, 7968)):
+        A2, B2 = torch.randn(M2, K2, generator=g), torch.randn(K2, N2, generator=g)
+        ref3 = A2.double() @ B2.double()
+        rms = {}
+        for compute in (0, 2, 3):
+            c3 = torch.empty(M2, N2, device="cuda")
+            ops.gemm(gpu(A2), gpu(B2), c3, compute=compute)
+            rms[compute] = float(((c3.double().cpu() - ref3) ** 2).mean().sqrt() / (ref3 ** 2).mean().sqrt())
+        print(f"K={K2}: relative rms error vs float64: f32 MFMA {rms[0]:.3e}, nine pairs {rms[2]:.3e}, six pairs {rms[3]:.3e}")
+        assert rms[2] <= 1.25 * rms[0] and rms[3] <= 1.25 * rms[0], (K2, rms)
     # row-group scale + split-K + accumulate through the split kernels
     rpg = 64
     asc = torch.rand(M // rpg, K, generator=g)
