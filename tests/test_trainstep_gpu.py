@@ -148,6 +148,15 @@ def test_sweeps_survive_foreign_kernels_holding_compute_units():
         ws2 = tr2.step(*batch, use_teacher_forcing=True)
         assert abs(tr2.read_stats(ws2)[0] - losses[i]) <= 1e-5 * abs(losses[i])
     assert _all_sweeps_ran(ws), "the decoder sweeps (one 96 KB workgroup per compute unit) are the grid most exposed to co-tenants"
+    # the last step's gradients agree tensor by tensor (1e-5 of each tensor's largest entry: the atomically accumulated split-K sums
+    # differ in their last bits from run to run), and so do the parameters after two Adam steps.
+    # Round 4: this comparison caught a real bug.  One run in five the FIRST step's embedding gradient beside the foreign kernel was
+    # scattered into row 0: the workspace's token rows are created by torch.zeros on the default stream, the step runs on the
+    # trainer's own non-blocking stream, and with most compute units held the zero-fill landed between that step's forward and
+    # backward pass (tests/tools/dbg_foreign.py).  TrainStep._ctx now waits for the device after creating a shape's buffers.
+    for k, gb in model2.store.grads().items():
+        ga = model.store.grads()[k]
+        assert float((ga - gb).abs().max()) <= 1e-5 * max(float(gb.abs().max()), 1e-6), k
     a, b = model.store.flat, model2.store.flat
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
