@@ -154,9 +154,10 @@ def test_sweeps_survive_foreign_kernels_holding_compute_units():
     # scattered into row 0: the workspace's token rows are created by torch.zeros on the default stream, the step runs on the
     # trainer's own non-blocking stream, and with most compute units held the zero-fill landed between that step's forward and
     # backward pass (tests/tools/dbg_foreign.py).  TrainStep._ctx now waits for the device after creating a shape's buffers.
-    for k, gb in model2.store.grads().items():
-        ga = model.store.grads()[k]
-        assert float((ga - gb).abs().max()) <= 1e-5 * max(float(gb.abs().max()), 1e-6), k
+    g1, g2 = model.store.grads(), model2.store.grads()
+    gmax = max(float(v.abs().max()) for v in g2.values())
+    for k, gb in g2.items():          # (a tensor whose gradient is zero in exact arithmetic - a bias in front of BatchNorm - holds 1e-9-size noise)
+        assert float((g1[k] - gb).abs().max()) <= 1e-5 * max(float(gb.abs().max()), 1e-3 * gmax), k
     a, b = model.store.flat, model2.store.flat
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
