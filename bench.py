@@ -449,7 +449,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true", help="skip the per-kernel timing loops (clean rocprof call counts)")
     ap.add_argument("--no-extra-workloads", action="store_true",
-                    help="skip the short deepspeech / las_large measurements the default (las_small, one GPU) run appends as extra_workloads")
+                    help="skip everything measured outside the timed region: the non-teacher-forced step, the other evaluations of an f32 product, "
+                         "the deepspeech / las_large measurements the default (las_small, one GPU) run appends as extra_workloads")
     ap.add_argument("--no-dp-path", action="store_true",
                     help="skip the short measurement of the data-parallel code path (single-rank RCCL group) the default one-GPU run appends as dp_path")
     ap.add_argument("--precision", choices=["f32", "bf16"], default=None,
@@ -605,7 +606,7 @@ def main():
     # of the previous logits back and cannot batch the embedding / vocabulary layer or take the decoder sweeps.  `value` is the
     # teacher-forced step (the path 99 % of the steps take); the off-path step is timed here, outside the timed region, and
     # `value_blended` weighs the two by the coin
-    if hasattr(model, "Hd") and world == 1:
+    if hasattr(model, "Hd") and world == 1 and not args.no_extra_workloads:
         try:
             k2 = max(3, min(args.steps, 6))
             for _ in range(3):

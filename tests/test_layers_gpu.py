@@ -283,7 +283,7 @@ def test_fused_attention_step_matches_oracle_and_two_kernel_path(B, T, Hd, D):
     assert int(fws[1].min()) == int(fws[1].max()) == 6 * 8       # 3 forward + 3 backward calls, 8 chunks each
 
 
-@pytest.mark.parametrize("R_,V", [(10, 3000), (64, 16000), (3, 120), (2, 40000)])
+@pytest.mark.parametrize("R_,V", [(10, 3000), (64, 16000), (3, 120), (2, 40000), (7, 3001), (5, 97), (33, 4100)])   # (vectorised rows, odd V: the scalar kernel, V beyond the LDS)
 def test_softmax_cross_entropy_loss_accuracy_gradient(R_, V):
     ops = _ops()
     g = torch.Generator().manual_seed(V)
