@@ -157,7 +157,7 @@ def test_sweeps_survive_foreign_kernels_holding_compute_units():
     g1, g2 = model.store.grads(), model2.store.grads()
     gmax = max(float(v.abs().max()) for v in g2.values())
     for k, gb in g2.items():          # (a tensor whose gradient is zero in exact arithmetic - a bias in front of BatchNorm - holds 1e-9-size noise)
-        assert float((g1[k] - gb).abs().max()) <= 1e-5 * max(float(gb.abs().max()), 1e-3 * gmax), k
+        assert float((g1[k] - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-6 * gmax, k
     a, b = model.store.flat, model2.store.flat
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
