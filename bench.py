@@ -31,16 +31,16 @@ PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 # SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
 WORKLOADS = {
-    # traffic: memory-side bytes per step from the PMC passes of profiles/r03_las_small_pmc_hbm_traffic.txt (MiB per step there:
-    # FETCH_SIZE 6700.1, WRITE_SIZE 3867.0; 2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate,
-    # measured offline; dominant_traffic: the same for one launch of rnn_sweep_bwd_kernel (FETCH 3213.71 / 3, WRITE 930.05 / 3 MiB); about 60 % of it
+    # traffic: memory-side bytes per step from the PMC passes of profiles/r04_las_small_pmc_hbm_traffic.txt (MiB per step there:
+    # FETCH_SIZE 6643.8, WRITE_SIZE 3862.2; 2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate,
+    # measured offline; dominant_traffic: the same for one launch of rnn_sweep_bwd_kernel (FETCH 3215.15 / 3, WRITE 930.05 / 3 MiB); about 60 % of it
     # is the inter-workgroup exchange of the one-launch sweeps (write-through stores, L1-bypassing polls), which the counters
     # tally at the fabric although the Infinity Cache serves it
     # algorithmic_bytes: activations kept for backward written once + read once (2 x 0.9 GB), logits 131 MB x 5 touches,
     # Adam 28 B x 16 M parameters, features 51 MB, every weight matrix read twice (forward product, input gradient)
-    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=(2 * 6700.1 + 3867.0) * 2 ** 20, algorithmic_bytes=3.1e9,
-                      traffic_source="offline rocprofv3 PMC passes, profiles/r03_las_small_pmc_hbm_traffic.txt (not measured in this run)",
-                      dominant_traffic=(2 * 3213.71 + 930.05) / 3 * 2 ** 20,
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=(2 * 6643.8 + 3862.2) * 2 ** 20, algorithmic_bytes=3.1e9,
+                      traffic_source="offline rocprofv3 PMC passes, profiles/r04_las_small_pmc_hbm_traffic.txt (not measured in this run)",
+                      dominant_traffic=(2 * 3215.15 + 930.05) / 3 * 2 ** 20,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
@@ -286,7 +286,13 @@ def kernel_rooflines(trainer, model, audio_d, n_d, precision):
         w = torch.randn(K, N, device="cuda") * 0.05
         y = torch.empty(M, N, device="cuda")
         t = time_kernel(trainer.stream, lambda: ops.gemm(a, w, y))
-        out.append(_mfma_entry(f"{gk} {label} [{M}x{K}]x[{K}x{N}]", 2.0 * M * K * N, t, peak))
+        extra = {}
+        if precision != "bf16" and ops.f32_gemm_mode() != "mfma":
+            # the f32 products run on the bf16 matrix pipe as 9 / 6 pair products each: `frac` stays the algorithmic f32 flops against the
+            # f32 MFMA peak (what the step needs, against what the f32 pipe would give); bf16_pipe_frac prices the executed pair products
+            pairs = 9 if ops.f32_gemm_mode() == "split9" else 6
+            extra = {"f32_products": ops.f32_gemm_mode(), "bf16_pipe_frac": round(pairs * 2.0 * M * K * N / t / PEAK_BF16_MFMA, 4)}
+        out.append(_mfma_entry(f"{gk} {label} [{M}x{K}]x[{K}x{N}]", 2.0 * M * K * N, t, peak, **extra))
 
     if is_las:
         He, Hd, V, T2 = model.He, model.Hd, model.V, ws.T2
