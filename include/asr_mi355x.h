@@ -321,6 +321,11 @@ int asr_rnn_cell_fwd(int rnn_type, int B, int H, int ndir, const asr_rnn_step_fw
 /* dst[i] = bf16(src[i]), round to nearest even: the bf16 weight images above (train.py:62-66 --mixed-precision:
  * with them the wide step kernels multiply bf16 weights by bf16-rounded states on the bf16 MFMA, f32 accumulation) */
 int asr_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+/* Transposed bf16 image with TIME-MAJOR columns - the layout asr_rnn_sweep_wide_bwd writes ds16T in: src is [nbatch][rows][cols] f32
+ * (batch stride batch_stride, row stride ld_src), dst[c][t * nbatch + b + dst_shift] = bf16(src[b][t][c] * scale[b][c]); scale
+ * (optional) is the Keras RNN input-dropout table [nbatch][cols].  dst_shift = nbatch pairs h[b, t - 1] with ds[b, t]. */
+int asr_f32_to_bf16_image_tb(const float* src, long ld_src, int nbatch, int rows, int cols, long batch_stride, const float* scale, void* dst,
+                             long ld_dst, long dst_shift, void* stream);
 /* dst[i] = float(src[i]) for a bf16 array (gradient buckets that were all-reduced as bf16) */
 int asr_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 /* Diagnostic: `blocks` workgroups of `threads` threads that do nothing for `microseconds` (<= 2 s, bounded by the real-time
@@ -404,7 +409,10 @@ typedef struct asr_rnn_seq_grad {
   float* ds[2];                             /* asr_rnn_sweep_bwd only: out, the gate-sum gradients [B,T,NS*H], a buffer of its own */
   float* db[2]; float* db_rec[2];           /* asr_rnn_sweep_bwd only, optional: bias gradients accumulated (+=) by the sweep itself - db [G*H] the
                                                column sums of the input-side slots of ds (Keras bias, GRU: bias[0]), db_rec [3H] GRU's
-                                               recurrent bias (bias[1]) - instead of a separate pass over ds                                */
+                                               recurrent bias (bias[1]) - instead of a separate pass over ds (asr_rnn_sweep_wide_bwd: db too)  */
+  void* ds16[2];                            /* asr_rnn_sweep_wide_bwd only, optional: the gate-sum gradients as a bf16 image [B T, 4H] ...   */
+  void* ds16T[2]; long ds16T_ld;            /* ... and transposed, bf16 [4H][ds16T_ld], column t * B + b (time-major; ds16T_ld % 4 == 0, >= B T):
+                                               the operands of the layer's dX / dW / dU products, written by the sweep itself; ds may then be NULL */
 } asr_rnn_seq_grad;
 /* After the call saved[d] holds the gate-sum gradients [B,T,NS*H] for the batched dW/dU/dX GEMMs (written in place over the
  * activations, one time step per launch).  asr_rnn_sweep_bwd writes them to g->ds[d] instead: its resident workgroups read the

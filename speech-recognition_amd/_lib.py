@@ -104,7 +104,8 @@ class DecoderSweepGrad(C.Structure):
 class RnnSeqGrad(C.Structure):
     _fields_ = [("dy", c_f32p), ("dy_ld", c_long), ("dh_last", c_f32p * 2), ("dh_last_ld", c_long * 2),
                 ("dc", c_f32p * 2), ("dy_carry", c_f32p * 2), ("direct", c_f32p * 2), ("dh0", c_f32p * 2),
-                ("dh0_ld", c_long * 2), ("ds", c_f32p * 2), ("db", c_f32p * 2), ("db_rec", c_f32p * 2)]
+                ("dh0_ld", c_long * 2), ("ds", c_f32p * 2), ("db", c_f32p * 2), ("db_rec", c_f32p * 2),
+                ("ds16", C.c_void_p * 2), ("ds16T", C.c_void_p * 2), ("ds16T_ld", c_long)]
 
 
 class ConvDesc(C.Structure):
@@ -158,6 +159,7 @@ SIGNATURES = {
     "asr_comm_destroy": (C.c_int, [_P]),
     "asr_allreduce_bucket": (C.c_int, [_P, _P, c_long, _P, _P]),
     "asr_f32_to_bf16_image": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, c_long, _P, C.c_int, C.c_int, _P, c_long, C.c_int, C.c_int, _P]),
+    "asr_f32_to_bf16_image_tb": (C.c_int, [_P, c_long, C.c_int, C.c_int, C.c_int, c_long, _P, _P, c_long, c_long, _P]),
     "asr_rnn_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(RnnGeom)]),
     "asr_rnn_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(c_long), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), _P, _P]),

@@ -321,8 +321,10 @@ __global__ __launch_bounds__(256) void bf16_image_kernel(const float* src, long 
 // bf16 pairs measured 1.5x SLOWER - 4-way LDS conflicts on the paired read and half the blocks in flight; this pass runs at ~3.1 TB/s.)
 // Destination column of source row r: (r / rpb) * drpb + r % rpb + dshift - the batches of a 3-D source can land at a different pitch and
 // offset (the recurrent-kernel gradient pairs h[b, t -+ 1] with ds[b, t]: the shifted h image then shares ds's transposed image).
+// tb_nb > 0: TIME-MAJOR columns.  The R = rows x tb_nb source rows are enumerated r = t * tb_nb + b (a tile's 64 rows are 64 batches of
+// one time step: their 256-byte pieces lie a batch stride apart), the destination column is r + dshift, the scale row is b.
 __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, long lds, int R, int Cc, int rpb, long bstr, const float* scale, int rpg,
-                                                           bf16_t* dst, long ldd, int drpb, int dshift) {
+                                                           bf16_t* dst, long ldd, int drpb, long dshift, int tb_nb) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -330,8 +332,14 @@ __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, lon
     const int r = r0 + i, c = c0 + tx;
     float v = 0.f;
     if (r < R && c < Cc) {
-      v = src[(long)(r / rpb) * bstr + (long)(r % rpb) * lds + c];
-      if (scale) v *= scale[(long)(r / rpg) * Cc + c];
+      if (tb_nb) {
+        const int t = r / tb_nb, b = r % tb_nb;
+        v = src[(long)b * bstr + (long)t * lds + c];
+        if (scale) v *= scale[(long)b * Cc + c];
+      } else {
+        v = src[(long)(r / rpb) * bstr + (long)(r % rpb) * lds + c];
+        if (scale) v *= scale[(long)(r / rpg) * Cc + c];
+      }
     }
     tile[i][tx] = v;
   }
@@ -340,7 +348,8 @@ __global__ __launch_bounds__(256) void bf16_image_t_kernel(const float* src, lon
     const int c = c0 + i, r = r0 + tx;
     if (c < Cc && r < R) {
       const __bf16 b = (__bf16)tile[tx][i];
-      dst[(long)c * ldd + (long)(r / rpb) * drpb + r % rpb + dshift] = __builtin_bit_cast(bf16_t, b);
+      const long col = tb_nb ? (long)r + dshift : (long)(r / rpb) * drpb + r % rpb + dshift;
+      dst[(long)c * ldd + col] = __builtin_bit_cast(bf16_t, b);
     }
   }
 }
@@ -356,7 +365,7 @@ extern "C" int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, in
   hipStream_t st = (hipStream_t)stream;
   if (transpose) {
     hipLaunchKernelGGL(bf16_image_t_kernel, dim3((unsigned)asr_cdiv(cols, 64), (unsigned)asr_cdiv(rows, 64)), dim3(256), 0, st, src, ld_src, rows, cols, rpb,
-                       batch_stride, scale, rows_per_group, static_cast<bf16_t*>(dst), ld_dst, drpb, dst_shift);
+                       batch_stride, scale, rows_per_group, static_cast<bf16_t*>(dst), ld_dst, drpb, (long)dst_shift, 0);
   } else {
     ASR_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && batch_stride % 4 == 0 && ld_dst % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0 &&
                   (!scale || ((uintptr_t)scale & 15) == 0),
@@ -366,6 +375,17 @@ extern "C" int asr_f32_to_bf16_image(const float* src, long ld_src, int rows, in
     hipLaunchKernelGGL(bf16_image_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, rows, cols, rpb, batch_stride, scale, rows_per_group,
                        static_cast<bf16_t*>(dst), ld_dst);
   }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_f32_to_bf16_image_tb(const float* src, long ld_src, int nbatch, int rows, int cols, long batch_stride, const float* scale, void* dst,
+                                        long ld_dst, long dst_shift, void* stream) {
+  ASR_CHECK(src && dst && nbatch > 0 && rows > 0 && cols > 0 && ld_src >= cols && dst_shift >= 0, ASR_ERR_ARG, "asr_f32_to_bf16_image_tb: bad argument");
+  ASR_CHECK((long)nbatch * rows < 2147483647L && ld_dst >= (long)nbatch * rows + dst_shift, ASR_ERR_SHAPE, "asr_f32_to_bf16_image_tb: destination rows too short");
+  const int R = nbatch * rows;
+  hipLaunchKernelGGL(bf16_image_t_kernel, dim3((unsigned)asr_cdiv(cols, 64), (unsigned)asr_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream, src, ld_src, R, cols,
+                     1, batch_stride, scale, 1, static_cast<bf16_t*>(dst), ld_dst, 1, dst_shift, nbatch);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

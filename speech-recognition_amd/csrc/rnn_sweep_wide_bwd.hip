@@ -51,7 +51,11 @@ struct WbDir {
   const float* saved;            // [B,T,4H] gate activations i, f, c~, o
   const float* cseq;             // [B,T,H]
   const float* c0; long c0_ld;   // initial cell state or null
-  float* ds;                     // [B,T,4H] out
+  float* ds;                     // [B,T,4H] out (f32), or null when the bf16 images below are wanted instead
+  unsigned short* ds16;          // optional: the same gate-sum gradients as a bf16 image [B T, 4H] (the A operand of dX = ds W^T)
+  unsigned short* ds16T;         // optional: ... transposed, [4H][ld16T] with column t * B + b (the B operand of dW = x^T ds and dU = h^T ds:
+  long ld16T;                    //   time-major columns, so that a step's 64 rows are ONE 128-byte run per gate column)
+  float* db;                     // optional: bias gradient [4H] += column sums of ds (summed in registers over the steps)
   const float* dh_last; long dh_last_ld;
   float* dc;                     // [B,H] in: d/d final c, out: d/d initial c
   float* dh0; long dh0_ld;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   const bool live = row < B;
   const bool writer = gj == 0;
   f32x4 dcv = {0.f, 0.f, 0.f, 0.f}, carry = {0.f, 0.f, 0.f, 0.f}, dirv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                              // this thread's share of the bias gradient (gate gj, its 4 units, its row)
   if (live) dcv = *reinterpret_cast<const f32x4*>(d.dc + (long)row * H + j0);
 
   // ---- product role: wave w owns output units 32 w .. 32 w + 31 of column block j (two M tiles); resident A operands ----
@@ -242,12 +247,36 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
       // the layer's ds: the four workgroups of a grid row hold the same values - column j stores gate j (one 16-byte store per lane;
       // all four gates from column 0 made its 32 workgroups 1.9 us per step slower than the rest, and everybody waits for the slowest)
       const int s = T - 1 - p, t = d.reverse ? T - 1 - s : s;
-      float* o = d.ds + ((long)row * T + t) * 4 * H + (long)gj * H + j0;
-      *reinterpret_cast<f32x4*>(o) = gj == 0 ? ds[0] : (gj == 1 ? ds[1] : (gj == 2 ? ds[2] : ds[3]));
+      const long o = ((long)row * T + t) * 4 * H + (long)gj * H + j0;
+      const f32x4 mine = gj == 0 ? ds[0] : (gj == 1 ? ds[1] : (gj == 2 ? ds[2] : ds[3]));
+      if (d.ds) *reinterpret_cast<f32x4*>(d.ds + o) = mine;
+      if (d.ds16) {                                                  // the straight bf16 image: what asr_f32_to_bf16_image would make of ds
+        const bf16x4_t h = {(__bf16)mine[0], (__bf16)mine[1], (__bf16)mine[2], (__bf16)mine[3]};
+        *reinterpret_cast<bf16x4_t*>(d.ds16 + o) = h;
+      }
+      bsum += mine;
     }
     fetch(p + 1, op);                                              // next step's operands: in flight during the product and the next gather
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS-only barrier: the image is complete
     if (*abort_now) break;                                          // (written before the barrier only: every wave reads the same value)
+    if (d.ds16T) {
+      // the transposed bf16 image, read back out of the LDS image: thread (unit u, row quad rq) takes gate gj of unit u for rows
+      // 4 rq .. 4 rq + 3 and stores them at [gate column][t B + row] - the 16 threads of a unit write one 128-byte run
+      const int s = T - 1 - p, t = d.reverse ? T - 1 - s : s;
+      const int u = tid >> 4, rq = tid & 15, k = 32 * gj + u;
+      const unsigned char* im = img[p & 1];
+      unsigned short v4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v4[e] = *reinterpret_cast<const unsigned short*>(im + wb_img(4 * rq + e, k >> 3) + (k & 7) * 2);
+      unsigned short* o = d.ds16T + (long)(gj * H + 32 * gi + u) * d.ld16T + (long)t * B + 4 * rq;
+      if ((B & 3) == 0) {
+        if (4 * rq < B) *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)v4[0] | ((unsigned)v4[1] << 16), (unsigned)v4[2] | ((unsigned)v4[3] << 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * rq + e < B) o[e] = v4[e];
+      }
+    }
     // ------------------------------------------------------------------------------------------ product + publish
     f32x4 acc[2][4];
 #pragma unroll
@@ -291,6 +320,19 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   __syncthreads();
   const int abort_flag = abort_par[0] | abort_par[1];
   if (live && writer && !abort_flag) *reinterpret_cast<f32x4*>(d.dc + (long)row * H + j0) = dcv;
+  if (d.db && !abort_flag) {
+    // bias gradient: the lanes 8 apart hold other rows of the same 4 units - sum them in the wave, then one atomic per element and wave
+    // (rows beyond B carry zeros)
+#pragma unroll
+    for (int s2 = 8; s2 < 64; s2 <<= 1) {
+      bsum.x += __shfl_xor(bsum.x, s2, 64); bsum.y += __shfl_xor(bsum.y, s2, 64);
+      bsum.z += __shfl_xor(bsum.z, s2, 64); bsum.w += __shfl_xor(bsum.w, s2, 64);
+    }
+    if (rl == 0) {
+      float* o = d.db + (long)gj * H + j0;
+      atomicAdd(o, bsum.x); atomicAdd(o + 1, bsum.y); atomicAdd(o + 2, bsum.z); atomicAdd(o + 3, bsum.w);
+    }
+  }
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     swd_record(a.err, (unsigned)abort_flag, 0);
@@ -336,15 +378,18 @@ extern "C" int asr_rnn_sweep_wide_bwd(const asr_rnn_seq* s, const asr_rnn_seq_gr
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   a.prio = asr_sweep_prio();
   for (int d = 0; d < s->ndir; ++d) {
-    ASR_CHECK(s->saved[d] && s->cseq[d] && s->U[d] && gs->ds[d] && gs->dc[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(s->saved[d] && s->cseq[d] && s->U[d] && gs->dc[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: null buffer (dir %d)", d);
+    ASR_CHECK(gs->ds[d] || gs->ds16[d] || gs->ds16T[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: no destination for the gate-sum gradients: ds, ds16 or ds16T (dir %d)", d);
     ASR_CHECK(gs->ds[d] != s->saved[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: ds must not alias the saved activations (dir %d)", d);
+    ASR_CHECK((((uintptr_t)gs->ds16[d] | (uintptr_t)gs->ds16T[d]) & 7) == 0 && (!gs->ds16T[d] || (gs->ds16T_ld % 4 == 0 && gs->ds16T_ld >= (long)s->B * s->T)),
+              ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: ds16 / ds16T must be 8-byte aligned, ds16T_ld a multiple of 4 and >= B T (dir %d)", d);
     ASR_CHECK(!s->rec_mult[d], ASR_ERR_UNSUPPORTED, "asr_rnn_sweep_wide_bwd: recurrent dropout is not supported (use asr_rnn_seq_bwd)");
     ASR_CHECK(s->ldu[d] % 4 == 0 && s->y_col[d] % 4 == 0 && (!s->c0[d] || s->c0_ld[d] % 4 == 0) && (!gs->dh_last[d] || gs->dh_last_ld[d] % 4 == 0) &&
                   (!gs->dh0[d] || gs->dh0_ld[d] % 4 == 0),
               ASR_ERR_SHAPE, "asr_rnn_sweep_wide_bwd: leading dimensions / column offsets must be multiples of 4 (dir %d)", d);
     // every one of these is read or written with 16-byte vector accesses: a misaligned view (an odd-offset slice of a state tensor)
     // must come back as an argument error, not as a fault on the device
-    const void* vec[] = {s->U[d], s->saved[d], s->cseq[d], s->c0[d], gs->ds[d], gs->dc[d], gs->dh_last[d], gs->dh0[d]};
+    const void* vec[] = {s->U[d], s->saved[d], s->cseq[d], s->c0[d], gs->ds[d], gs->dc[d], gs->dh_last[d], gs->dh0[d]};      // (null = unused: passes)
     for (const void* q : vec)
       ASR_CHECK(((uintptr_t)q & 15) == 0, ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: U, saved, cseq, c0, ds, dc, dh_last and dh0 must be 16-byte aligned (dir %d)", d);
     WbDir& p = a.d[d];
@@ -352,6 +397,8 @@ extern "C" int asr_rnn_sweep_wide_bwd(const asr_rnn_seq* s, const asr_rnn_seq_gr
     p.saved = s->saved[d]; p.cseq = s->cseq[d];
     p.c0 = s->c0[d]; p.c0_ld = s->c0_ld[d];
     p.ds = gs->ds[d];
+    p.ds16 = static_cast<unsigned short*>(gs->ds16[d]); p.ds16T = static_cast<unsigned short*>(gs->ds16T[d]); p.ld16T = gs->ds16T_ld;
+    p.db = gs->db[d];
     p.dh_last = gs->dh_last[d]; p.dh_last_ld = gs->dh_last_ld[d];
     p.dc = gs->dc[d];
     p.dh0 = gs->dh0[d]; p.dh0_ld = gs->dh0_ld[d];

@@ -310,8 +310,13 @@ class BiRNN:
                                     and ops.device_exclusive() and ops.rnn_sweep_wide_bwd_supported(rt, B, T, H, 2)
                                     and torch.cuda.get_device_properties(device).multi_processor_count >= 256)
         if buf["wide_bwd_mode"]:
+            # the sweep writes the gate-sum gradients as the two bf16 images the layer's products read (round 4: otherwise three image
+            # passes over a 0.5 GB f32 ds per direction): straight [B T, 4H] for dX = ds W^T, transposed [4H][K8] with time-major columns
+            # for dW = x^T ds and dU = h^T ds; the K padding is zeroed here and never written
+            K8 = (B * T + 7) // 8 * 8
             for dd in buf["dirs"]:
-                dd["ds"] = f(B, T, NS[rt] * H)
+                dd["ds16"] = torch.empty(B * T, NS[rt] * H, device=device, dtype=torch.bfloat16)
+                dd["ds16T"] = torch.zeros(NS[rt] * H, K8, device=device, dtype=torch.bfloat16)
         return buf
 
     def final_states(self, buf):
@@ -415,10 +420,12 @@ class BiRNN:
             gb = self.store.g[self.names[d] + "bias"]
             gds.append(dict(dh_last=dfinal_h[d], dc=dc_bufs[d] if rt == "lstm" else None,
                             dy_carry=dd["dy_carry"] if buf["mask"] is not None else None, direct=dd["direct"], dh0=dd["dh0"],
-                            ds=dd["ds"] if (pws is not None or wide) else None,
-                            # the BPTT sweep sums the bias gradients itself (no second pass over ds)
-                            db=(gb[0] if rt == "gru" else gb) if pws is not None else None, db_rec=gb[1] if (rt == "gru" and pws is not None) else None))
-        dskey = "ds" if (pws is not None or wide) else "saved"     # where this backward pass leaves the gate-sum gradients
+                            ds=dd["ds"] if pws is not None else None,
+                            ds16=dd["ds16"] if wide else None, ds16T=dd["ds16T"] if wide else None,
+                            # the BPTT sweeps sum the bias gradients themselves (no second pass over ds)
+                            db=(gb[0] if rt == "gru" else gb) if (pws is not None or wide) else None,
+                            db_rec=gb[1] if (rt == "gru" and pws is not None) else None))
+        dskey = "ds" if pws is not None else "saved"               # where this backward pass leaves the f32 gate-sum gradients (wide: bf16 images only)
         if wide:
             sweep = lambda: ops.rnn_sweep_wide_bwd(buf["seq"], dy3d, gds, buf["wide_bwd_ws"], getattr(self.store, "err_flag", None))
         else:
@@ -461,9 +468,36 @@ class BiRNN:
                     if rt == "gru":
                         ops.colsum(ds2[:, sl * H:(sl + 1) * H], gb[1][cb * H:(cb + 1) * H])
 
+        def param_grads_wide(only=None):
+            """dW = x^T ds, dU = h_prev^T ds from the transposed bf16 image the wide sweep wrote (time-major columns t B + b): x and the
+            shifted h take the same column order (ops.f32_to_bf16_image_tb); the initial state fills the one column block of the h image
+            that has no predecessor inside the sequence, so it needs no product of its own."""
+            x3 = buf["x3d"]
+            for d, dd in enumerate(buf["dirs"]):
+                if only is not None and d != only:
+                    continue
+                nm = self.names[d]
+                mt = dd["mtab"] if buf["drop"] else None
+                dsT = dd["ds16T"]
+                xT = ops.f32_to_bf16_image_tb(x3, ops.image_scratch("xT_tb", self.Din, B * T, layout=(B, T)), scale=mt)
+                ops.gemm_bf16_nt(xT, dsT, g[nm + "kernel"], accumulate=1)
+                hs = dd["hseq"]
+                # (a scratch per layer and direction: the column block of the initial state is written by the layers that have one only)
+                hT = ops.image_scratch("hT_tb", H, B * T, layout=(B, T, self.prefix, d))
+                if T > 1:
+                    if dd["reverse"]:
+                        ops.f32_to_bf16_image_tb(hs[:, 1:], hT, dst_shift=0)
+                    else:
+                        ops.f32_to_bf16_image_tb(hs[:, :T - 1], hT, dst_shift=B)
+                if dd["h0"] is not None:
+                    ops.f32_to_bf16_image_tb(dd["h0"].unsqueeze(1), hT, dst_shift=(T - 1) * B if dd["reverse"] else 0)
+                ops.gemm_bf16_nt(hT, dsT, g[nm + "recurrent_kernel"], accumulate=1)
+
         def param_grads(only=None):      # reads x, ds, hseq, h0, the dropout table of THIS layer only; writes this layer's gradients
             if buf["rdrop"]:
                 return param_grads_per_gate()
+            if wide:
+                return param_grads_wide(only)
             shared = rt == "lstm" and T > 1 and ops.bf16_images_pay(H, 4 * H, B * (T - 1)) and ops.bf16_images_pay(self.Din, 4 * H, B * T)
             for d, dd in enumerate(buf["dirs"]):
                 if only is not None and d != only:
@@ -523,6 +557,12 @@ class BiRNN:
                 for k, (sl, cb, mi) in enumerate(gate_in):
                     ops.gemm(ds2[:, sl * H:(sl + 1) * H], W[:, cb * H:(cb + 1) * H], dx3d.view(B * T, self.Din), trans_b=True,
                              accumulate=1 if (dx_accumulate or d == 1 or k > 0) else 0, c_scale=dd["mtab_g"][mi] if buf["drop"] else None, c_rpg=T)
+        elif dx3d is not None and wide:
+            for d, dd in enumerate(buf["dirs"]):                    # dX (+)= ds W^T straight from the sweep's bf16 image of ds
+                mt = dd["mtab"] if buf["drop"] else None
+                W = p[self.names[d] + "kernel"]
+                W16 = ops.f32_to_bf16_image(W, ops.image_scratch("b", self.Din, NG[rt] * H))
+                ops.gemm_bf16_nt(dd["ds16"], W16, dx3d.view(B * T, self.Din), accumulate=1 if (dx_accumulate or d == 1) else 0, c_scale=mt, c_rpg=T)
         elif dx3d is not None:
             for d, dd in enumerate(buf["dirs"]):
                 mt = dd["mtab"] if buf["drop"] else None

@@ -384,6 +384,17 @@ def f32_to_bf16_image(src, dst, *, transpose=False, scale=None, rows_per_group=0
     return dst
 
 
+def f32_to_bf16_image_tb(src3d, dst, *, scale=None, dst_shift=0):
+    """Transposed bf16 image with TIME-MAJOR columns (asr_f32_to_bf16_image_tb): src3d f32 [nbatch, rows, cols] (any batch / row strides, unit
+    inner stride) -> dst bf16 [cols, >= nbatch * rows + dst_shift], dst[c][t * nbatch + b + dst_shift] = bf16(src3d[b, t, c] * scale[b, c]) - the
+    column order of the transposed ds image the wide BPTT sweep writes."""
+    assert src3d.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src3d.dim() == 3 and src3d.stride(2) == 1 and dst.stride(-1) == 1
+    nb, rows, cols = src3d.shape
+    check(lib().asr_f32_to_bf16_image_tb(_p(src3d), src3d.stride(1), nb, rows, cols, src3d.stride(0), _p(scale) if scale is not None else None,
+                                         C.c_void_p(dst.data_ptr()), dst.stride(0), int(dst_shift), _stream()))
+    return dst
+
+
 def bf16_images_pay(M, N, K) -> bool:
     """Whether ops.gemm would route an [M,K] x [K,N] product through bf16 images (mixed precision, large in every dimension)."""
     md = _bf16_images["min_dim"]
@@ -648,11 +659,18 @@ def _rnn_seq_grad(dy, dirs_grad):
     g.ds = _arr2([d.get("ds") for d in dirs_grad])
     g.db = _arr2([d.get("db") for d in dirs_grad])
     g.db_rec = _arr2([d.get("db_rec") for d in dirs_grad])
+    g.ds16 = _arr2([d.get("ds16") for d in dirs_grad])
+    g.ds16T = _arr2([d.get("ds16T") for d in dirs_grad])
+    lds = [d["ds16T"].stride(0) for d in dirs_grad if d.get("ds16T") is not None]
+    assert len(set(lds)) <= 1
+    g.ds16T_ld = lds[0] if lds else 0
     return g
 
 
 def rnn_sweep_wide_bwd(seq, dy, dirs_grad, ws, err_flag=None):
-    """The wide layer's BPTT in one launch; dirs_grad as for rnn_seq_bwd, with `ds` [B,T,4H] tensors of their own (out)."""
+    """The wide layer's BPTT in one launch; dirs_grad as for rnn_seq_bwd, with `ds` [B,T,4H] tensors of their own (out) and / or the bf16
+    images the layer's products read: `ds16` bf16 [B*T, 4H], `ds16T` bf16 [4H, K8] (columns t * B + b, zero-initialised padding), and
+    optionally `db` [4H] (+= the bias gradient)."""
     g = _rnn_seq_grad(dy, dirs_grad)
     check(lib().asr_rnn_sweep_wide_bwd(C.byref(seq), C.byref(g), _p(ws), _p(err_flag), _stream()))
 

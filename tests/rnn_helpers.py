@@ -88,11 +88,32 @@ class HipBiRNN:
         if wide:
             assert ops.rnn_sweep_wide_bwd_supported(self.rt, B, T, H, len(self.dirs))
             wws = ops.rnn_sweep_wide_bwd_ws(B, H, len(self.dirs))
+            images = wide == "images"          # the sweep writes the bf16 images of ds (straight + transposed, time-major) and the bias sums itself
+            K8 = (B * T + 7) // 8 * 8
             for dd, g in zip(self.dirs, gds):
-                g["ds"] = dd["ds"] = torch.full_like(dd["saved"], float("nan"))
+                if images:
+                    g["ds16"] = torch.full((B * T, 4 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+                    g["ds16T"] = torch.zeros(4 * H, K8, device="cuda", dtype=torch.bfloat16)
+                    g["db"] = torch.zeros(4 * H, device="cuda")
+                else:
+                    g["ds"] = dd["ds"] = torch.full_like(dd["saved"], float("nan"))
             ops.rnn_sweep_wide_bwd(self.seq, gpu(dy), gds, wws)
             torch.cuda.synchronize()
             assert not ops.rnn_persist_error(wws), f"wide backward sweep: a hand-off timed out: {ops.sweep_diagnosis(wws, 'rnn_sweep_wide_bwd')}"
+            if images:
+                for dd, g in zip(self.dirs, gds):
+                    ds16 = g["ds16"].float().view(B, T, 4 * H)
+                    assert bool(torch.isfinite(ds16).all()), "the straight image must be written for every (row, step)"
+                    # transposed image: column t * B + b of gate-unit row k holds ds16[b, t, k]; the K padding stays zero
+                    tr = g["ds16T"].float()
+                    assert torch.equal(tr[:, :B * T].view(4 * H, T, B).permute(2, 1, 0), ds16), "transposed image != straight image"
+                    assert float(tr[:, B * T:].abs().max() if K8 > B * T else 0.0) == 0.0
+                    # bias sums: f32 sums of the unrounded values against the sum of the bf16-rounded ones
+                    ref_db = ds16.double().sum((0, 1))
+                    err = float((g["db"].double() - ref_db).abs().max()) / max(float(ref_db.abs().max()), 1e-30)
+                    assert err < 2e-2, f"bias sums {err:.2e}"
+                    dd["ds"] = ds16
+                    dd["db_sweep"] = g["db"]
             persistent = True                                     # (ds is in dd["ds"])
         else:
             ops.rnn_seq_bwd(self.seq, gpu(dy), gds, pws)

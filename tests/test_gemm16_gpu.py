@@ -204,3 +204,42 @@ def test_birnn_backward_shared_image_path_survives_a_change_of_batch_geometry():
         ops._bf16_images["on"] = True
         ops._bf16_images["min_dim"] = old
         ops.set_mixed_precision(False)
+
+
+def test_time_major_transposed_image_pairs_x_and_shifted_h_with_a_time_major_ds_image():
+    """asr_f32_to_bf16_image_tb: dst[c][t * B + b + shift] = bf16(src[b, t, c] * scale[b, c]) - the column order of the transposed ds image the wide
+    BPTT sweep writes (round 4).  dW = x^T ds with the dropout table folded in, dU = h_prev^T ds with the shifted h image whose free column
+    block takes the initial state, both against float64 sums over the rounded operands; strided batch views."""
+    from speech_recognition_amd import ops
+    g = torch.Generator().manual_seed(19)
+    Bq, T, D, H, N = 6, 21, 96, 64, 128
+    K = Bq * T
+    K8 = (K + 7) // 8 * 8
+    x = torch.randn(Bq, T, D, generator=g).cuda()
+    hs_big = torch.randn(Bq, T + 3, H, generator=g).cuda()
+    hs = hs_big[:, 2:T + 2]                                           # a strided batch view
+    h0 = torch.randn(Bq, H, generator=g).cuda()
+    ds = torch.randn(Bq, T, N, generator=g).cuda()
+    tab = ((torch.rand(Bq, D, generator=g) > 0.3).float() / 0.7).cuda()
+    dsT = torch.zeros(N, K8, device="cuda", dtype=torch.bfloat16)
+    dsT[:, :K] = ds.permute(2, 1, 0).reshape(N, K).to(torch.bfloat16)   # [n][t * B + b]
+    xT = torch.zeros(D, K8, device="cuda", dtype=torch.bfloat16)
+    ops.f32_to_bf16_image_tb(x, xT, scale=tab)
+    want = (x * tab[:, None]).to(torch.bfloat16).float().permute(2, 1, 0).reshape(D, K)
+    assert torch.equal(xT[:, :K].float(), want) and float(xT[:, K:].float().abs().max() if K8 > K else 0.0) == 0.0
+    gW = torch.zeros(D, N, device="cuda")
+    ops.gemm_bf16_nt(xT, dsT, gW, accumulate=1)
+    _check(gW, torch.einsum("btd,btn->dn", _bf(x * tab[:, None]), _bf(ds)), x, ds)
+    for reverse in (False, True):
+        hT = torch.zeros(H, K8, device="cuda", dtype=torch.bfloat16)
+        if reverse:
+            ops.f32_to_bf16_image_tb(hs[:, 1:], hT, dst_shift=0)
+            ops.f32_to_bf16_image_tb(h0.unsqueeze(1), hT, dst_shift=(T - 1) * Bq)
+            hprev = torch.cat([hs[:, 1:], h0[:, None]], 1)
+        else:
+            ops.f32_to_bf16_image_tb(hs[:, :T - 1], hT, dst_shift=Bq)
+            ops.f32_to_bf16_image_tb(h0.unsqueeze(1), hT, dst_shift=0)
+            hprev = torch.cat([h0[:, None], hs[:, :T - 1]], 1)
+        gU = torch.zeros(H, N, device="cuda")
+        ops.gemm_bf16_nt(hT, dsT, gU, accumulate=1)
+        _check(gU, torch.einsum("bth,btn->hn", _bf(hprev), _bf(ds)), hprev, ds)

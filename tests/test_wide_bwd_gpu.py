@@ -33,18 +33,20 @@ def test_wide_bwd_sweep_equals_the_staged_step_kernels(B, T, masked, states):
     ops.set_mixed_precision(True)
     try:
         outs = []
-        for wide in (False, True):
+        for wide in (False, True, "images"):       # "images": ds leaves the sweep as the two bf16 images + bias sums (round 4) instead of f32
             hip = HipBiRNN("lstm", x, mask, fwd, bwd, init)
             hip.forward(persistent=False)
             outs.append(hip.backward(dy, dst, wide=wide))
     finally:
         ops.set_mixed_precision(False)
-    for d in range(2):
-        ref, got = outs[0][d], outs[1][d]
-        for key in ("dW", "dU", "db", "dx", "dh0", "dc0"):
-            assert torch.isfinite(got[key]).all(), (d, key)
-            err = _rel(got[key], ref[key])
-            assert err < 1e-2, f"direction {d} {key}: relative L2 {err:.2e}"
+    for which in (1, 2):
+        for d in range(2):
+            ref, got = outs[0][d], outs[which][d]
+            for key in ("dW", "dU", "db", "dx", "dh0", "dc0"):
+                assert torch.isfinite(got[key]).all(), (d, key)
+                err = _rel(got[key], ref[key])
+                # (the images carry ds rounded to bf16: the reference products here use the unrounded f32 ds of the step kernels)
+                assert err < (1e-2 if which == 1 else 1.5e-2), f"{'f32 ds' if which == 1 else 'bf16 images'}: direction {d} {key}: relative L2 {err:.2e}"
 
 
 def test_wide_bwd_sweep_timeout_is_reported_not_hung():
