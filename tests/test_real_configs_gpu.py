@@ -278,7 +278,8 @@ def test_deepspeech_yml_training_step_at_full_geometry(B):
 
 
 # ---------------------------------------------------------------------------------------------- las_large.yml (H = 1024)
-MIXED_GRAD_L2 = 1e-1      # whole-model gradients under mixed precision against the bf16-operand oracle (see the comment in the test)
+MIXED_GRAD_L2 = 1.5e-1      # whole-model gradients under mixed precision against the bf16-operand oracle: measured 5.6e-2 .. 1.06e-1 for the worst
+                            # tensor from run to run (rounding-boundary flips decide it: see the comment in the test); round 3's bound stays
 
 
 def _stagewise_encoder_check(model, ws, leaves, mc, seed):
