@@ -124,7 +124,8 @@ typedef struct asr_gemm_desc {
 int asr_gemm_f32(const asr_gemm_desc* d, const float* A, const float* B, float* C, void* stream);
 /* Process-wide choice of how the CONVOLUTIONS (asr_conv2d_*) evaluate their f32 products: 0 the f32 MFMA, 2 / 3 nine / six bf16 pair
  * products of exact three-way operand splits on the bf16 MFMA (asr_gemm_desc.compute has the definitions; a GEMM carries its own
- * choice per call).  Returns the previous mode.  Default: the environment variable ASR_GEMM_F32 = mfma | split9 | split6. */
+ * choice per call).  Returns the previous mode (0, 2 or 3), or a negative asr_status for a bad argument.  Default: the environment variable
+ * ASR_GEMM_F32 = mfma | split9 | split6 (split6 when unset). */
 int asr_set_f32_product_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------

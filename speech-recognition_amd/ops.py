@@ -254,7 +254,9 @@ def set_f32_gemm_mode(name: str):
     """'mfma' | 'split9' | 'split6' (see above); returns the previous name."""
     old = next(k for k, v in _F32_MODES.items() if v == _f32_mode["compute"])
     _f32_mode["compute"] = _F32_MODES[name]
-    check(lib().asr_set_f32_product_mode(_F32_MODES[name]) * 0)      # the convolutions follow (process-wide switch of the library)
+    prev = lib().asr_set_f32_product_mode(_F32_MODES[name])          # the convolutions follow (process-wide switch of the library)
+    if prev < 0:                                                        # (>= 0: the previous mode; negative: an asr_status)
+        check(prev)
     return old
 
 
