@@ -202,3 +202,32 @@ def test_search_surfaces_a_sweep_timeout():
         searcher.greedy_search(audio)
     toks2, _ = searcher.greedy_search(audio)                  # raised once, cleared
     assert torch.equal(toks, toks2)
+
+
+def test_training_trajectory_is_the_same_under_every_evaluation_of_an_f32_product():
+    """Round 4: the dense products and convolutions run on the bf16 matrix pipe as six (default) or nine exact bf16 pair products per f32
+    product, f32 accumulation (gemm_core.h run_split) - or on the f32 MFMA.  Forty optimizer steps of a LAS model (two 16-row batch tiles, all
+    sweeps, dropout, captured graphs) from the same seed under each evaluation: the loss curves agree to 5e-4 relative at every step (the
+    evaluations differ from each other by less than each differs from float64: tests/test_gemm_gpu.py), and the loss falls."""
+    from speech_recognition_amd import ops
+    batch = _las_batch(B=32, T=126, L=6, seed=2)
+    curves = {}
+    old = ops.f32_gemm_mode()
+    try:
+        for mode in ("mfma", "split9", "split6"):
+            ops.set_f32_gemm_mode(mode)
+            tr, model = _las_trainer(He=64, seed=5, use_graph=True)
+            losses = []
+            for _ in range(40):
+                ws = tr.step(*batch, use_teacher_forcing=True)
+                losses.append(tr.read_stats(ws)[0])
+            curves[mode] = np.array(losses)
+            assert _all_sweeps_ran(ws)
+    finally:
+        ops.set_f32_gemm_mode(old)
+    ref = curves["mfma"]
+    assert ref[-1] < 0.9 * ref[0], "the model must be learning for the comparison to mean anything"
+    for mode in ("split9", "split6"):
+        rel = np.abs(curves[mode] - ref) / np.abs(ref)
+        print(f"{mode}: largest relative loss difference to the f32 MFMA over 40 steps {rel.max():.2e} (final losses {curves[mode][-1]:.5f} / {ref[-1]:.5f})")
+        assert rel.max() < 5e-4, (mode, rel.max())
