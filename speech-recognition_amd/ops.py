@@ -247,6 +247,8 @@ _compute = {"gemm": 0}
 # of both operands on the bf16 MFMA (2^-32 relative per product - tighter than an f32 FMA chain - f32 accumulation); "split6" = 3,
 # the same without the three pairs of weight <= 2^-24.  ASR_GEMM_F32 selects it.
 _F32_MODES = {"mfma": 0, "split9": 2, "split6": 3}
+if os.environ.get("ASR_GEMM_F32", "split6") not in _F32_MODES:
+    raise ValueError(f"ASR_GEMM_F32={os.environ['ASR_GEMM_F32']!r}: expected one of {sorted(_F32_MODES)}")
 _f32_mode = {"compute": _F32_MODES[os.environ.get("ASR_GEMM_F32", "split6")]}
 
 
