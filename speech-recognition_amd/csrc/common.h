@@ -24,6 +24,16 @@ void asr_set_error(const char* fmt, ...);
       return (code);                        \
     }                                       \
   } while (0)
+// The opt-in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute) lives with each DEVICE's copy of the code object, so a call site sets
+// it on the first use per device, not per process: `seen` is that call site's bit mask over device ordinals.  (A race sets it twice.)
+static inline bool asr_first_use_on_device(unsigned long long& seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (seen & bit) return false;
+  seen |= bit;
+  return true;
+}
 #define ASR_LAUNCH_CHECK()                                              \
   do {                                                                  \
     hipError_t e__ = hipGetLastError();                                 \

@@ -203,11 +203,10 @@ extern "C" int asr_ctc_loss(float* logits, long ld, const int32_t* labels, int B
   float* gamma = alpha + n;
   const size_t rowbytes = sizeof(float) * (size_t)V;
   const bool in_lds = rowbytes <= 144 * 1024;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;
+  if (asr_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_grad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
   }
   ASR_CHECK(sizeof(float) * 2 * S <= 64 * 1024, ASR_ERR_SHAPE, "asr_ctc_loss: label length %d too long", L);
   if (in_lds) hipLaunchKernelGGL(ctc_rows_kernel<true>, dim3((unsigned)(B * T)), dim3(256), rowbytes, st, (const float*)logits, ld, labels, T, V, L, blank, lse, lp);

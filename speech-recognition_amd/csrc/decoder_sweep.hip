@@ -641,11 +641,10 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
   a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_DELAY")) : 8;   // negative: timing experiment, gathers do not wait
   const size_t smem = ds_lds_bytes(s->Hd, s->D);
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;
+  if (asr_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   // one launch per 32 batch rows (the grid is 32 rows x 8 chunks of attention and 2 batch tiles of cells): the passes are independent
   // chains over the same U steps, each as long as one launch - twice the time for B = 64, against 9 launches per step on the fallback

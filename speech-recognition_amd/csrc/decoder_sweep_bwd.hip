@@ -712,11 +712,10 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
   a.prio = asr_sweep_prio();
   a.delay = getenv("ASR_DECODER_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_BWD_DELAY")) : 4;
   const size_t smem = db_lds_bytes(s->Hd, s->D, nt);
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;
+  if (asr_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_sweep_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
   }
   a.Bs = s->B;
   for (int b0 = 0; b0 < s->B; b0 += 32) {                 // one launch per 32 batch rows (see asr_decoder_sweep_fwd)

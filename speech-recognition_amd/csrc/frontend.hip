@@ -359,12 +359,11 @@ extern "C" int asr_logmel_features(const asr_logmel_cfg* cfg, const float* audio
   a.audio = audio; a.n_samples = n_samples; a.tw = tw; a.melw = melw; a.melrange = melrange; a.seed = seed; a.out = out;
   a.dct = melw + (long)a.bins * a.nmel;
   a.B = B; a.n_max = n_max; a.T_out = T_out;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (asr_first_use_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   dim3 grid((unsigned)asr_cdiv(T_out, 16 * MT - 2), (unsigned)B);
   if (MT == 4) hipLaunchKernelGGL(logmel_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a);

@@ -151,18 +151,16 @@ extern "C" int asr_softmax_xent(float* logits, long ld, const int32_t* labels, i
   hipStream_t st = (hipStream_t)stream;
   const size_t bytes = sizeof(float) * (size_t)V;
   if (bytes <= 144 * 1024 && V % 4 == 0 && ld % 4 == 0 && ((uintptr_t)logits & 15) == 0) {
-    static bool attr_v = false;
-    if (!attr_v) {
+    static unsigned long long attr_v = 0;
+    if (asr_first_use_on_device(attr_v)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_vec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_v = true;
     }
     hipLaunchKernelGGL(softmax_xent_vec_kernel, dim3((unsigned)R), dim3(256), bytes, st, logits, ld, labels, R, V, ignore_index, stats, write_grad,
                        grad_scale);
   } else if (bytes <= 144 * 1024) {
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0;
+    if (asr_first_use_on_device(attr)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_xent_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr = true;
     }
     hipLaunchKernelGGL(softmax_xent_kernel<true>, dim3((unsigned)R), dim3(256), bytes, st, logits, ld, labels, R, V, ignore_index, stats,
                        write_grad, grad_scale);

@@ -525,8 +525,8 @@ static void launch_fwd_wide(int rnn_type, const FwdArgs& a, int ndir, hipStream_
   dim3 grid((unsigned)asr_cdiv(asr_cdiv(a.H, 4), NQ), (unsigned)asr_cdiv(a.B, 16 * NT), (unsigned)ndir);
   const size_t smem = sizeof(float) * NW * NT * NQ * 16 * 17;
   auto go = [&](auto kern) {
-    static bool attr = false;                                  // one flag per kernel instantiation (generic lambda)
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static unsigned long long attr = 0;                                  // one flag per kernel instantiation (generic lambda)
+    if (asr_first_use_on_device(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, st, a);
   };
   bool bf = true;

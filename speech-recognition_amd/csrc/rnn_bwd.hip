@@ -580,8 +580,8 @@ static void launch_bwd_wide(int rnn_type, const Bwd2Args& a, int ndir, int nu, b
   dim3 grid((unsigned)asr_cdiv(nu, 16 * NU), (unsigned)asr_cdiv(a.B, 16 * NT), (unsigned)ndir);
   const size_t smem = sizeof(float) * (two ? 2 : 1) * BW_NW * NT * NU * 256;
   auto go = [&](auto kern) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static unsigned long long attr = 0;
+    if (asr_first_use_on_device(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     hipLaunchKernelGGL(kern, grid, dim3(64 * BW_NW), smem, st, a);
   };
   bool bf = true;                                                // every used source carries a bf16 image of its weights
@@ -637,8 +637,8 @@ static int launch_bwd(int rnn_type, const Bwd2Args& a, int ndir, hipStream_t st)
     if (ok) {
       dim3 grid((unsigned)asr_cdiv(nu, 32), (unsigned)asr_cdiv(a.B, 16), (unsigned)ndir);
       auto go = [&](auto kern, size_t smem) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static unsigned long long attr = 0;
+        if (asr_first_use_on_device(attr)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         hipLaunchKernelGGL(kern, grid, dim3(64 * BW_NW), smem, st, a);
       };
       if (bf) {

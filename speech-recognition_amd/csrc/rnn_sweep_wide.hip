@@ -359,12 +359,11 @@ extern "C" int asr_rnn_sweep_wide_fwd(const asr_rnn_seq* s, float* ws, float* er
   dim3 grid((unsigned)(H / 8), 1, (unsigned)s->ndir);
   const int ks = H / 128;
   const size_t smem = sizeof(float) * 2 * 4 * 4 * 2 * 16 * 17 + (size_t)4 * ks * 2 * 64 * 16;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long attr = 0;
+  if (asr_first_use_on_device(attr)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_sweepw_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
   }
   if (ks == 8) hipLaunchKernelGGL(rnn_sweepw_fwd_kernel<8>, grid, dim3(384), smem, st, a);
   else if (ks == 6) hipLaunchKernelGGL(rnn_sweepw_fwd_kernel<6>, grid, dim3(384), smem, st, a);

@@ -320,9 +320,10 @@ class TrainStep:
         ops.advance_state(m.state, m.store.err_flag)
 
     def _segments(self, c, teacher):
-        """The step as a list of stream-ordered callables; gradient bucket k is complete after
-        segment k+1 (segment 0 = front end + forward + loss).  A single replica exchanges nothing: its whole backward
-        pass is one segment (one captured graph instead of one per bucket)."""
+        """The step as a list of stream-ordered callables.  With torch.distributed collectives (not capturable around the bucket
+        hand-over): segment 0 = front end + forward + loss, then one segment per gradient bucket (bucket k is complete after segment
+        k+1), the update after the last all-reduce.  A single replica, and replicas on the library's own capturable collectives
+        (ASR_NATIVE_COLLECTIVE=1), run the whole step as ONE callable = one captured graph."""
         segs = [lambda: self._fwd_loss(c, teacher)]
         bsegs = self.model.backward_segments(c["ws"], c["feats"])
         if self.segmented and self.one_graph:
@@ -332,16 +333,24 @@ class TrainStep:
                 m = self.model
                 buckets = m.store.bucket_views()
                 done = m.bucket_schedule() if hasattr(m, "bucket_schedule") else [[k] for k in range(len(buckets))]
+                self._fwd_loss(c, teacher)
                 for k, fn in enumerate(bsegs):
                     fn()
                     for b in done[k]:
                         self.exchange.reduce_async(buckets[b])
                 self.exchange.wait()
-            segs.append(whole)
+                self._update()
+            return [whole]
         elif self.segmented:
             segs += bsegs
         else:
-            segs.append(lambda: [fn() for fn in bsegs])
+            # one replica: forward, backward and the update are ONE callable = one captured graph per step (round 4; three before)
+            def whole_step():
+                self._fwd_loss(c, teacher)
+                for fn in bsegs:
+                    fn()
+                self._update()
+            return [whole_step]
         return segs
 
     def _run_segment(self, c, teacher, k, fn):
@@ -403,7 +412,8 @@ class TrainStep:
                     for b in done[k - 1]:
                         self.exchange.reduce_async(buckets[b])
             self.exchange.wait()
-            self._run_segment(c, teacher, "update", self._update)
+            if self.segmented and not self.one_graph:
+                self._run_segment(c, teacher, "update", self._update)
         m.weights_changed()
         self.iterations += 1
         return c["ws"]

@@ -217,8 +217,8 @@ def test_data_parallel_code_path_on_one_gpu_with_a_single_rank_rccl_group():
         pytest.fail(r[1])
     for mixed, runs in r[1].items():
         single, again = runs["single"], runs["single_again"]
-        assert single["graphs"] == 3 and runs["dp"]["graphs"] == 2 + (2 + CFG["num_encoder_layers"]), (single["graphs"], runs["dp"]["graphs"])
-        assert runs["dp_native"]["graphs"] == 3, "native collectives: forward, backward with the collectives inside, update"
+        assert single["graphs"] == 1 and runs["dp"]["graphs"] == 2 + (2 + CFG["num_encoder_layers"]), (single["graphs"], runs["dp"]["graphs"])
+        assert runs["dp_native"]["graphs"] == 1, "native collectives: forward, backward with the collectives inside and the update, one graph"
         scale = np.abs(single["flat"]).max()
         noise = np.abs(single["flat"] - again["flat"]).max() / scale
         for name in ("dp", "dp_native"):
