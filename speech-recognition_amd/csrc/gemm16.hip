@@ -14,30 +14,11 @@
 // flight across the barrier (one barrier per K tile): 913 TF on the weight-gradient shape against 789 for the fallback.
 // Fallback (any K multiple of 8; configuration 0): tile 128 x 128 x 64, 4 waves as 2 x 2, global -> registers -> LDS staging with
 // the next tile's loads in flight during the MFMAs (as gemm_core.h).  LDS rows of 64 bf16 = 128 B, the 16-byte chunk index XORed
-// with (row & 7) so that the 32 rows a half-wave reads at one k offset fall on different banks.
+// with ((row >> 1) & 7) so that each 16-lane group of a ds_read_b128 covers the bank row exactly once (g16_off).
 // The images are produced by memory-bound conversion passes (f32 -> bf16, optionally times the Keras input-dropout row-group
 // table, optionally TRANSPOSED: the weight-gradient products contract over the rows of both activations): ~0.1 ms per
 // 31936 x 2048 activation against ~1-3 ms of product saved.  Epilogue = gemm_core.h's (bias, ReLU, row-group scale, +=, atomics).
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "gemm_core.h"
-
-typedef unsigned short bf16_t;
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-#define G16_BK 64
-
-template <int I, int N, class F>
-__device__ __forceinline__ void g16_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    g16_static_for<I + 1, N>(f);
-  }
-}
-
-__device__ __forceinline__ int g16_off(int row, int ch) { return row * 128 + 16 * (ch ^ (row & 7)); }   // byte offset of chunk ch (8 bf16) of a tile row
+#include "gemm16.h"
 
 // WM x WN waves, each TM x TN MFMA tiles of 32 x 32: block tile (32 WM TM) x (32 WN TN) x 64.  NBUF LDS buffers: with 2 the tile for step
 // kt + 1 is written into the other buffer BEFORE the MFMAs of step kt and the loads of tile kt + 2 are issued right after (one barrier per
@@ -58,10 +39,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
   const int kbeg = zs * k_chunk, kend = min(K, kbeg + k_chunk);
   if (kbeg >= K) return;
   // XCD-aware tile order (gemm.hip): blocks b, b + 8 share an XCD; every XCD walks a contiguous range, the smaller operand fastest
-  const int total = tiles_m * tiles_n;
-  const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-  const int p = xcd * (total >> 3) + min(xcd, total & 7) + idx;
-  const int bm = p / tiles_n, bn = p - bm * tiles_n;
+  int bm, bn;
+  g16_tile(blockIdx.x, tiles_m, tiles_n, bm, bn);
   const int m0 = bm * BM, n0 = bn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,7 +101,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
     constexpr int NW = WM * WN;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "glds map");
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;             // dest row within its 8-row group, SOURCE chunk for dest position lane & 7
+    static_assert(NW % 2 == 0, "the source swizzle below takes the row group's parity from the wave");
+    // dest row within its 8-row group; SOURCE chunk for dest position lane & 7 of row 8 g + r8, g = wave + NW i (g_swz of that row)
+    const int r8 = lane >> 3, c8 = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
     auto stage = [&](int k0, int buf) {
       unsigned char* As = g16_smem + buf * (BM + BN) * 128;
       unsigned char* Bs = As + BM * 128;
@@ -208,9 +189,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm16_nt_kernel(const bf16_t* A
 }
 
 static hipError_t g16_attr_status = hipSuccess;                 // last hipFuncSetAttribute result of g16_launch (checked by the caller)
-struct G16Launch {
-  const bf16_t *A, *B; GemmEpilogue ep; const asr_gemm_desc* d; int sk; hipStream_t st;
-};
 template <int WM, int WN, int TM, int TN, int NBUF, int STG>
 static void g16_launch(const G16Launch& g) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -264,12 +242,25 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
   }
   if (d->accumulate == 2 || sk > 1) mode = 2;
   GemmEpilogue ep{C, d->ldc, d->M, d->N, d->alpha, d->bias, d->c_scale, d->c_rpg, mode, d->relu, nullptr, 0u, 0.f};
-  const G16Launch g{static_cast<const bf16_t*>(A16), static_cast<const bf16_t*>(B16), ep, d, sk, (hipStream_t)stream};
+  G16Launch g{static_cast<const bf16_t*>(A16), static_cast<const bf16_t*>(B16), ep, d, sk, (hipStream_t)stream};
   const bool whole = d->K % G16_BK == 0;                        // (k_chunk is a multiple of 64 by construction)
   int cfg = g16_config();
-  // by shape: the three-buffer pipeline pays with many K tiles per workgroup (weight / input gradients, K >= 2048); products with a
-  // short K and a large C ([8128 x 1024] x [1024 x 16000]: 459 against 540 us) are bound by writing C and want more, smaller workgroups
-  if (cfg == 100) cfg = (d->K / sk >= 2048) ? 12 : 0;
+  // by shape: the deep pipelines pay with many K tiles per workgroup (weight / input gradients, K >= 2048); products with a
+  // short K and a large C ([8128 x 1024] x [1024 x 16000]: 419 against 476 us) are bound by writing C and want more, smaller workgroups
+  if (cfg == 100) {
+    cfg = (d->K / sk >= 2048) ? 12 : 0;
+    if (whole && d->K / sk >= 2048 && d->M >= 256 && d->N >= 256) {
+      cfg = 15;                                                  // the eight-phase 256 x 256 schedule (gemm16_8p.hip)
+      // A grid short of the chip (the 256 x 256 tiles of a weight gradient number 64-128): split K further where C is accumulated anyway -
+      // the partial sums then meet in atomic adds ([2048 x 31936] x [31936 x 4096]: 615 us in one piece, 448 us in two)
+      const long tiles = (long)asr_cdiv(d->M, 256) * asr_cdiv(d->N, 256) * d->batch;
+      if (mode != 0) {
+        int s2 = sk;
+        while (tiles * s2 * 2 <= 288 && d->K / (s2 * 2) >= 2048) s2 *= 2;
+        if (s2 != sk) { g.sk = s2; g.ep.mode = 2; }
+      }
+    }
+  }
   if (!whole && cfg >= 4) cfg = 0;
   if (cfg >= 12 && cfg <= 14 && asr_cdiv(d->K, sk) < 3 * G16_BK) cfg = 0;   // (the three-buffer pipeline wants at least three K tiles)
   switch (cfg) {
@@ -287,6 +278,7 @@ extern "C" int asr_gemm_bf16_nt(const asr_gemm_desc* d, const void* A16, const v
     case 13: g16_launch<2, 2, 2, 2, 3, 1>(g); break;             // 128 x 128, 4 waves, three buffers
     case 14: g16_launch<2, 2, 4, 2, 3, 1>(g); break;             // 256 x 128, 4 waves of 128 x 64, three buffers
     case 11: g16_launch<2, 2, 4, 2, 1, 1>(g); break;
+    case 15: g16_attr_status = g16_launch_8p(g); break;                            // 256 x 256, 8 waves, eight-phase schedule
     default: g16_launch<2, 2, 2, 2, 1, 0>(g); break;             // 128 x 128, 4 waves, one LDS buffer, register staging (any K; the fallback of 12)
   }
   if (g16_attr_status != hipSuccess && cfg != 0) {

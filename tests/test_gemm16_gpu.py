@@ -19,7 +19,7 @@ def _check(got, want, a, b):
     assert err <= 1e-4 * scale, (err, scale)
 
 
-@pytest.fixture(params=range(15))
+@pytest.fixture(params=range(16))
 def tile_config(request):
     """Every tile configuration of the kernel (register / direct-to-LDS staging, one / two LDS buffers, 128 / 256-row tiles)."""
     from speech_recognition_amd import ops
