@@ -20,7 +20,7 @@
 // Needs whole K tiles (K and the K chunk multiples of 64); rows beyond M / N are clamped on load and dropped by the epilogue.
 // ABL: timing experiments only (results wrong unless 0 or 1) - 1 no stagger, 2 no direct-to-LDS loads inside the loop, 3 no fragment reads inside
 // the loop, 4 no MFMAs, 5 no priority raise, 6 neither stagger nor priority
-template <int ABL>
+template <int ABL, int MF>
 __global__ __launch_bounds__(512) void gemm16_8p_kernel(const bf16_t* A, long lda, const bf16_t* B, long ldb, GemmEpilogue ep, int M, int N, int K,
                                                         int tiles_m, int tiles_n, int split_k, int k_chunk, long sAz, long sBz, long sCz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char g16_smem[];     // [buffer 2][A0 A1 B0 B1][128 rows][128 B]
@@ -58,50 +58,55 @@ __global__ __launch_bounds__(512) void gemm16_8p_kernel(const bf16_t* A, long ld
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  // fragment reads: this lane's byte offset inside a half tile for MFMA k-step s (chunk 2 s + lh, swizzled by its row)
-  int xo[4];
+  // fragment reads: this lane's byte offsets inside a half tile.  MF = 32 (v_mfma_f32_32x32x16_bf16): lane = (row l & 31, chunk 2 s + (l >> 5)) for
+  // k-step s of 4, a wave's quadrant = 2 m tiles x 1 n tile; MF = 16 (v_mfma_f32_16x16x32_bf16): lane = (row l & 15, chunk 4 s + (l >> 4)) for k-step
+  // s of 2, quadrant = 4 m tiles x 2 n tiles.  Same 8 + 4 reads and the same arithmetic per phase; the 16 x 16 form holds a higher clock on
+  // random operands (MI355X_MICROARCH.md, DVFS give-back (7)).
+  constexpr int KS = MF == 32 ? 4 : 2, MT = MF == 32 ? 2 : 4, NT = MF == 32 ? 1 : 2;
+  const int lrow = MF == 32 ? l31 : (lane & 15), lk = MF == 32 ? lh : (lane >> 4);
+  int xo[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) xo[s] = g16_off(l31, 2 * s + lh);
+  for (int s = 0; s < KS; ++s) xo[s] = g16_off(lrow, (8 / KS) * s + lk);
   const int arow = wr * 64 * 128, brow = 32768 + wc * 32 * 128;
-  bf16x8 a[2][4], b0[4], b1[4];
+  bf16x8 a[MT][KS], b0[NT][KS], b1[NT][KS];
   bool first = true;
   auto rdA = [&](int buf, auto half) {
     if (ABL == 3 && !first) return;
     const unsigned char* base = g16_smem + buf * 65536 + decltype(half)::value * 16384 + arow;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a[i][s] = *reinterpret_cast<const bf16x8*>(base + i * 4096 + xo[s]);
+      for (int s = 0; s < KS; ++s) a[i][s] = *reinterpret_cast<const bf16x8*>(base + i * MF * 128 + xo[s]);
   };
-  auto rdB = [&](int buf, auto half, bf16x8 (&b)[4]) {
+  auto rdB = [&](int buf, auto half, bf16x8 (&b)[NT][KS]) {
     if (ABL == 3 && !first) return;
     const unsigned char* base = g16_smem + buf * 65536 + decltype(half)::value * 16384 + brow;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = *reinterpret_cast<const bf16x8*>(base + xo[s]);
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) b[j][s] = *reinterpret_cast<const bf16x8*>(base + j * MF * 128 + xo[s]);
   };
-  f32x16 acc[4][2];                                            // [A half * 2 + m tile][B half]
+  typedef typename std::conditional<MF == 32, f32x16, f32x4>::type acc_t;
+  acc_t acc[2][MT][2][NT];                                     // [A half][m tile][B half][n tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * MT * 2 * NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto quad = [&](auto ha, auto hb, bf16x8 (&b)[4]) {          // first barrier .. second barrier of a phase
+    for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) (&acc[0][0][0][0])[i][r] = 0.f;
+  auto quad = [&](auto ha, auto hb, bf16x8 (&b)[NT][KS]) {     // first barrier .. second barrier of a phase
     constexpr int HA = decltype(ha)::value, HB = decltype(hb)::value;
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL != 5 && ABL != 6) __builtin_amdgcn_s_setprio(1);
-    if (ABL != 4) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[HA * 2 + i][HB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[s], acc[HA * 2 + i][HB], 0, 0, 0);
-    } else {
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(a[i][s]), "v"(b[s]));
-    }
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (ABL == 4) asm volatile("" ::"v"(a[i][s]), "v"(b[j][s]));
+          else if constexpr (MF == 32) acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], b[j][s], acc[HA][i][HB][j], 0, 0, 0);
+          else acc[HA][i][HB][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b[j][s], acc[HA][i][HB][j], 0, 0, 0);
+        }
     if (ABL != 5 && ABL != 6) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   };
@@ -144,14 +149,15 @@ __global__ __launch_bounds__(512) void gemm16_8p_kernel(const bf16_t* A, long ld
   for (; t + 2 < nk; ++t) tile(t, std::true_type{});
   for (; t < nk; ++t) tile(t, std::false_type{});
   if (ABL != 1 && ABL != 6 && wr == 0) __builtin_amdgcn_s_barrier();                   // (the barrier the late group is still owed)
-  g16_static_for<0, 4>([&](auto i) {
-    g16_static_for<0, 16>([&](auto r) {
-      constexpr int ic = decltype(i)::value, rc = decltype(r)::value;
-      const int row = m0 + (ic >> 1) * 128 + wr * 64 + (ic & 1) * 32 + (rc & 3) + 8 * (rc >> 2) + 4 * lh;
+  // C: MF = 32: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5); MF = 16: col = l & 15, row = 4 (l >> 4) + r
+  g16_static_for<0, 2 * MT>([&](auto i) {
+    g16_static_for<0, (MF == 32 ? 16 : 4)>([&](auto r) {
+      constexpr int ic = decltype(i)::value, rc = decltype(r)::value, ha = ic / MT, mt = ic % MT;
+      const int row = m0 + ha * 128 + wr * 64 + mt * MF + (MF == 32 ? (rc & 3) + 8 * (rc >> 2) + 4 * lh : 4 * lk + rc);
       const long srow2 = ep.map_row(row);
-      g16_static_for<0, 2>([&](auto j) {
-        constexpr int jc = decltype(j)::value;
-        ep.put(row, srow2, n0 + jc * 128 + wc * 32 + l31, acc[ic][jc][rc]);
+      g16_static_for<0, 2 * NT>([&](auto j) {
+        constexpr int jc = decltype(j)::value, hb = jc / NT, nt = jc % NT;
+        ep.put(row, srow2, n0 + hb * 128 + wc * 32 + nt * MF + lrow, acc[ha][mt][hb][nt][rc]);
       });
     });
   });
@@ -159,8 +165,9 @@ __global__ __launch_bounds__(512) void gemm16_8p_kernel(const bf16_t* A, long ld
 
 hipError_t g16_launch_8p(const G16Launch& g) {
   static const int abl = getenv("ASR_G16_8P_ABL") ? atoi(getenv("ASR_G16_8P_ABL")) : 0;
-  auto kern = abl == 1 ? gemm16_8p_kernel<1> : abl == 2 ? gemm16_8p_kernel<2> : abl == 3 ? gemm16_8p_kernel<3> : abl == 4 ? gemm16_8p_kernel<4>
-            : abl == 5 ? gemm16_8p_kernel<5> : abl == 6 ? gemm16_8p_kernel<6> : gemm16_8p_kernel<0>;
+  static const int mf = getenv("ASR_G16_8P_MFMA") ? atoi(getenv("ASR_G16_8P_MFMA")) : 16;
+  auto kern = abl == 1 ? gemm16_8p_kernel<1, 16> : abl == 2 ? gemm16_8p_kernel<2, 16> : abl == 3 ? gemm16_8p_kernel<3, 16> : abl == 4 ? gemm16_8p_kernel<4, 16>
+            : abl == 5 ? gemm16_8p_kernel<5, 16> : abl == 6 ? gemm16_8p_kernel<6, 16> : mf == 32 ? gemm16_8p_kernel<0, 32> : gemm16_8p_kernel<0, 16>;
   static unsigned long long seen = 0;
   if (asr_first_use_on_device(seen)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
