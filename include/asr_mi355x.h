@@ -145,6 +145,14 @@ int asr_conv2d_fwd(const asr_conv_desc* d, const float* x, const float* w, const
 int asr_conv2d_bwd_filter(const asr_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
 /* dx = full correlation of dy with w (overwrites dx) */
 int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, const float* w, float* dx, void* stream);
+/* The same forward pass / input gradient for kernels that slide with stride 1 along W over 32-channel multiples (deepspeech2.py:47-50, conv2 and
+ * conv3): every input row is staged in LDS once per kernel row and shared by the kw taps (csrc/conv_halo.hip).  asr_conv2d_halo_workspace returns
+ * the bytes of device scratch the call needs for the re-ordered kernel (which: 0 forward, 1 input gradient), or 0 when the geometry or the
+ * product mode (asr_set_f32_product_mode 0) takes the general entry points above; the *_halo calls then return ASR_ERR_UNSUPPORTED.  Same
+ * results as asr_conv2d_fwd / asr_conv2d_bwd_data up to the order of the f32 accumulation.  No dropout epilogue. */
+long asr_conv2d_halo_workspace(const asr_conv_desc* d, int which);
+int asr_conv2d_fwd_halo(const asr_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, void* stream);
+int asr_conv2d_bwd_data_halo(const asr_conv_desc* d, const float* dy, const float* w, float* dx, void* ws, long ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Memory-bound layer kernels

@@ -229,6 +229,7 @@ static int conv_mode() {
   }
   return g_conv_mode;
 }
+int conv_product_mode() { return conv_mode(); }               // (conv_halo.hip)
 extern "C" int asr_set_f32_product_mode(int mode) {
   ASR_CHECK(mode == 0 || mode == 2 || mode == 3, ASR_ERR_ARG, "asr_set_f32_product_mode: 0 (f32 MFMA), 2 (nine bf16 pair products) or 3 (six), got %d", mode);
   const int old = conv_mode();

@@ -861,6 +861,24 @@ def conv_out_dims(d):
     return ho.value, wo.value
 
 
+# Scratch of the row-staged convolutions (csrc/conv_halo.hip: the kernel re-ordered and split into bf16 planes, rewritten by every call), one buffer
+# per (geometry, pass, stream): calls on one stream are ordered, calls on different streams must not share it.
+_conv_halo_scratch = {}
+
+
+def _conv_halo_ws(d, which):
+    """(buffer, bytes) for asr_conv2d_*_halo, or None when the geometry / product mode takes the general kernels."""
+    need = lib().asr_conv2d_halo_workspace(C.byref(d), which)
+    if need <= 0 or _f32_mode["compute"] == 0:
+        return None
+    key = (d.B, d.H, d.W, d.C, d.kh, d.kw, d.sh, d.sw, d.O, which, torch.cuda.current_stream().cuda_stream)
+    buf = _conv_halo_scratch.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device="cuda")
+        _conv_halo_scratch[key] = buf
+    return buf, need
+
+
 def conv2d_fwd(x, w, bias, strides, y=None, seed=None, drop_stream=0, drop_rate=0.0):
     _dev(x, name="x"), _dev(w, name="w")
     d = conv_desc(x.shape, w.shape, strides)
@@ -868,6 +886,10 @@ def conv2d_fwd(x, w, bias, strides, y=None, seed=None, drop_stream=0, drop_rate=
     if y is None:
         y = torch.empty(d.B, Ho, Wo, d.O, device=x.device, dtype=torch.float32)
     assert x.is_contiguous() and w.is_contiguous() and y.is_contiguous()
+    ws = _conv_halo_ws(d, 0) if not drop_rate > 0 and x.data_ptr() % 16 == 0 else None
+    if ws is not None:
+        check(lib().asr_conv2d_fwd_halo(C.byref(d), _p(x), _p(w), _p(bias), _p(y), C.c_void_p(ws[0].data_ptr()), ws[1], _stream()))
+        return y
     check(lib().asr_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(seed) if drop_rate > 0 else None, drop_stream,
                                float(drop_rate), _stream()))
     return y
@@ -883,6 +905,10 @@ def conv2d_bwd_filter(x, dy, dw, strides):
 def conv2d_bwd_data(dy, w, dx, strides):
     d = conv_desc(dx.shape, w.shape, strides)
     assert dx.is_contiguous() and dy.is_contiguous() and w.is_contiguous()
+    ws = _conv_halo_ws(d, 1) if dy.data_ptr() % 16 == 0 else None
+    if ws is not None:
+        check(lib().asr_conv2d_bwd_data_halo(C.byref(d), _p(dy), _p(w), _p(dx), C.c_void_p(ws[0].data_ptr()), ws[1], _stream()))
+        return dx
     check(lib().asr_conv2d_bwd_data(C.byref(d), _p(dy), _p(w), _p(dx), _stream()))
     return dx
 

@@ -32,6 +32,12 @@ CONV_CASES = [
     # partitions that add up atomically in a dX the call zeroes first (round 3); 96 channels: 64x64 forward, 128x128 filter-gradient tiles
     ((2, 60, 25, 32), (21, 11, 32, 32), (2, 1)),
     ((2, 44, 25, 32), (21, 11, 32, 96), (2, 1)),
+    # the row-staged kernels (csrc/conv_halo.hip: stride 1 along W, 32-channel multiples) off the deepspeech geometry: 40 output channels (a ragged
+    # 32-wide tile), stride 3 along H (three classes of the input gradient, one of them with a single kernel row), 12 taps, 64 input channels
+    # (two chunks per kernel row), row groups that do not fill the last workgroup
+    ((3, 37, 19, 32), (5, 4, 32, 40), (3, 1)),
+    ((1, 23, 40, 64), (7, 12, 64, 32), (1, 1)),
+    ((2, 9, 30, 32), (2, 2, 32, 32), (4, 1)),
 ]
 
 
