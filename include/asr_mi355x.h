@@ -151,6 +151,9 @@ int asr_conv2d_bwd_data(const asr_conv_desc* d, const float* dy, const float* w,
  * product mode (asr_set_f32_product_mode 0) takes the general entry points above; the *_halo calls then return ASR_ERR_UNSUPPORTED.  Same
  * results as asr_conv2d_fwd / asr_conv2d_bwd_data up to the order of the f32 accumulation.  No dropout epilogue. */
 long asr_conv2d_halo_workspace(const asr_conv_desc* d, int which);
+/* The row-staged kernels run one long workgroup per compute unit, so a geometry whose workgroups leave the last round of 256 mostly empty keeps the
+ * general kernels (workspace 0).  asr_conv2d_halo_force(1) lifts that gate (tests, tuning), (0) restores it, (-1) only reads; returns the old value. */
+int asr_conv2d_halo_force(int on);
 int asr_conv2d_fwd_halo(const asr_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, long ws_bytes, void* stream);
 int asr_conv2d_bwd_data_halo(const asr_conv_desc* d, const float* dy, const float* w, float* dx, void* ws, long ws_bytes, void* stream);
 

@@ -200,6 +200,7 @@ SIGNATURES = {
     "asr_conv2d_bwd_filter": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "asr_conv2d_bwd_data": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "asr_conv2d_halo_workspace": (C.c_long, [C.POINTER(ConvDesc), C.c_int]),
+    "asr_conv2d_halo_force": (C.c_int, [C.c_int]),
     "asr_conv2d_fwd_halo": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_long, _P]),
     "asr_conv2d_bwd_data_halo": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_long, _P]),
     "asr_fill_f32": (C.c_int, [_P, c_long, C.c_float, _P]),

@@ -51,9 +51,25 @@ def f32_product_mode(request):
     ops.set_f32_gemm_mode(old)
 
 
-@pytest.mark.parametrize("xs,ws,st", CONV_CASES)
-def test_conv2d_forward_and_gradients(xs, ws, st, f32_product_mode):
+@pytest.fixture(params=["general", "row_staged"])
+def conv_route(request):
+    """The general implicit-GEMM kernels (csrc/conv.hip) and, where the geometry allows them, the row-staged ones (csrc/conv_halo.hip) with the
+    occupancy gate lifted - by default a test-sized problem never fills the 256 workgroups that gate asks for."""
     ops = _ops()
+    old = ops.lib().asr_conv2d_halo_force(1 if request.param == "row_staged" else 0)
+    yield request.param
+    ops.lib().asr_conv2d_halo_force(old)
+
+
+@pytest.mark.parametrize("xs,ws,st", CONV_CASES)
+def test_conv2d_forward_and_gradients(xs, ws, st, f32_product_mode, conv_route):
+    ops = _ops()
+    if conv_route == "row_staged":
+        d = ops.conv_desc(xs, ws, st)
+        import ctypes
+        routed = [ops.lib().asr_conv2d_halo_workspace(ctypes.byref(d), k) > 0 for k in (0, 1)]
+        if f32_product_mode == "mfma" or not any(routed):
+            pytest.skip("this case takes the general kernels on both routes")
     g = torch.Generator().manual_seed(sum(xs) + sum(ws))
     x = torch.randn(xs, generator=g, dtype=torch.float64, requires_grad=True)
     w = torch.randn(ws, generator=g, dtype=torch.float64, requires_grad=True)
