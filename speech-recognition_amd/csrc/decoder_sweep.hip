@@ -101,9 +101,9 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   float* hblk = part + 2 * 4 * 272;                    // [64] previous state of the owned (row, unit) pairs
   float* cblk = hblk + 64;                             // [64] previous cell state of the owned pairs
   int* flags = reinterpret_cast<int*>(cblk + 64);      // abort | cC (slice ready) | per-wave progress words of the four hand-over points
-  volatile int* abort_flag = flags;
-  volatile int* cC = flags + 1;
-  volatile int *cE = flags + 4, *cA = flags + 8, *cB = flags + 12, *cD = flags + 16;   // scores, partial, slices gathered, sums
+  const lds_flag_t abort_flag = lds_flag(flags);          // (LDS-typed: ds_read / ds_write, not flat accesses - sweep_common.h)
+  const lds_flag_t cC = abort_flag + 1;
+  const lds_flag_t cE = abort_flag + 4, cA = abort_flag + 8, cB = abort_flag + 12, cD = abort_flag + 16;   // scores, partial, slices gathered, sums
   if (tid < 20) flags[tid] = 0;
   if (tid < DS_MAXTC2) esc[tid] = -INFINITY;
   if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)

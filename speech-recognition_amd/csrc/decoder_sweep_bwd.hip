@@ -48,7 +48,7 @@ struct DbArgs {
 };
 
 // up to 9 self-validating pieces per lane (layer 1: 4 partial-dH pieces, 4 dq pieces, 1 dc piece)
-__device__ __forceinline__ bool db_gather9(const float* base, const unsigned (&off)[9], const bool (&use)[9], f32x4 (&v)[9], volatile int* abort_flag,
+__device__ __forceinline__ bool db_gather9(const float* base, const unsigned (&off)[9], const bool (&use)[9], f32x4 (&v)[9], lds_flag_t abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000) {
     // the probe piece is chosen with wave-uniform branches over STATIC indices (a run-time pick from the offset array goes
@@ -91,7 +91,7 @@ __device__ __forceinline__ bool db_gather9(const float* base, const unsigned (&o
 }
 
 // the five-piece gather of decoder_sweep_common.h with the static probe choice
-__device__ __forceinline__ bool db_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], volatile int* abort_flag,
+__device__ __forceinline__ bool db_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], lds_flag_t abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000) {
     if (__any(use[0])) { if (!ds_probe(base, off[0], use[0], abort_flag, limit, code)) return false; }
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
   float* ps = des + DS_MAXTC2;                         // [64] attention weights of the chunk
   float* dqs = ps + DS_MAXTC2;                         // [256] partial query gradient
   int* flags = reinterpret_cast<int*>(dqs + 256);      // [64]
-  volatile int* abort_flag = flags;
-  volatile int *cG = flags + 4, *cO = flags + 8, *cS = flags + 12, *cA1 = flags + 16, *cA2 = flags + 20, *cA3 = flags + 24, *cA4 = flags + 28;
+  const lds_flag_t abort_flag = lds_flag(flags);          // (LDS-typed: ds_read / ds_write, not flat accesses - sweep_common.h)
+  const lds_flag_t cG = abort_flag + 4, cO = abort_flag + 8, cS = abort_flag + 12, cA1 = abort_flag + 16, cA2 = abort_flag + 20, cA3 = abort_flag + 24, cA4 = abort_flag + 28;
   if (tid < 64) flags[tid] = 0;
   if (tid == 0) swd_arrive(a.err);                       // start handshake (sweep_common.h)
   swd_setprio(a.prio);

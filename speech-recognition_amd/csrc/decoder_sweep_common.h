@@ -21,7 +21,7 @@ __device__ __forceinline__ bool ds_fresh(const f32x4& v) {
   return __float_as_uint(v.x) != DS_SENT && __float_as_uint(v.y) != DS_SENT && __float_as_uint(v.z) != DS_SENT && __float_as_uint(v.w) != DS_SENT;
 }
 // code | (step << 8): 1 h1 gather, 2 partial gather, 3 context gather, 4 h0 gather, 5-8 LDS hand-overs
-__device__ __forceinline__ bool ds_wait(volatile int* c, int target, volatile int* abort_flag, int limit, int code) {
+__device__ __forceinline__ bool ds_wait(lds_flag_t c, int target, lds_flag_t abort_flag, int limit, int code) {
   for (int i = 0; *c < target; ++i) {
     if (*abort_flag) return false;
     if (i > limit) { *abort_flag = code; return false; }
@@ -33,7 +33,7 @@ __device__ __forceinline__ bool ds_wait(volatile int* c, int target, volatile in
 // microsecond of each other, so the first one is a good predictor): 256 workgroups x 4 waves re-reading 5-8 KB each per microsecond
 // for the several microseconds a role waits for its turn would put terabytes per second of polls in front of the publishes.
 // Addresses are (wave-uniform base in SGPRs, 32-bit byte offset per lane): half the address registers of flat pointers.
-__device__ __forceinline__ bool ds_probe(const float* base, unsigned off, bool use, volatile int* abort_flag, int limit, int code) {
+__device__ __forceinline__ bool ds_probe(const float* base, unsigned off, bool use, lds_flag_t abort_flag, int limit, int code) {
   for (int spins = 0;; ++spins) {
     f32x4 v;
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(base) : "memory");
@@ -45,7 +45,7 @@ __device__ __forceinline__ bool ds_probe(const float* base, unsigned off, bool u
   }
 }
 // up to 5 self-validating 16-byte pieces per lane: re-read until none of the USED ones holds the sentinel
-__device__ __forceinline__ bool ds_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], volatile int* abort_flag,
+__device__ __forceinline__ bool ds_gather5(const float* base, const unsigned (&off)[5], const bool (&use)[5], f32x4 (&v)[5], lds_flag_t abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000) {
     // the probe piece is the first one any lane uses - chosen with wave-uniform branches over STATIC indices (a run-time pick
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool ds_gather5(const float* base, const unsigned (&o
     __builtin_amdgcn_s_sleep(1);
   }
 }
-__device__ __forceinline__ bool ds_gather8(const float* base, const unsigned (&off)[8], const bool (&use)[8], f32x4 (&v)[8], volatile int* abort_flag,
+__device__ __forceinline__ bool ds_gather8(const float* base, const unsigned (&off)[8], const bool (&use)[8], f32x4 (&v)[8], lds_flag_t abort_flag,
                                            int limit, int delay, int code) {
   if (delay >= 0 && delay < 1000 && !ds_probe(base, off[0], use[0], abort_flag, limit, code)) return false;
   for (int spins = 0;; ++spins) {
@@ -116,11 +116,11 @@ __device__ __forceinline__ bool ds_gather8(const float* base, const unsigned (&o
 // Hand-overs inside the workgroup: every gather wave keeps its OWN progress word per hand-over point (the step it has finished,
 // plus one); a waiter needs all four.  (One shared cumulative counter is not enough here: a gather wave that has nothing to
 // gather at some point of the step runs ahead, and its increments for LATER steps would complete the count of an earlier one.)
-__device__ __forceinline__ void ds_mark(volatile int* c4, int wave, int value) {
+__device__ __forceinline__ void ds_mark(lds_flag_t c4, int wave, int value) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) c4[wave] = value;
 }
-__device__ __forceinline__ bool ds_wait4(volatile int* c4, int target, volatile int* abort_flag, int limit, int code) {
+__device__ __forceinline__ bool ds_wait4(lds_flag_t c4, int target, lds_flag_t abort_flag, int limit, int code) {
   for (int i = 0;; ++i) {
     const int v = c4[threadIdx.x & 3];
     if (__all(v >= target)) return true;

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * (5 + NQ)) void rnn_sweep_fwd_kernel(SwArgs a) 
             ok = ok && __float_as_uint(av[i].x) != SW_SENT && __float_as_uint(av[i].y) != SW_SENT && __float_as_uint(av[i].z) != SW_SENT &&
                  __float_as_uint(av[i].w) != SW_SENT;
         if (__all(ok) || (a.dbg & 2)) break;
-        if (*(volatile int*)&abort_flag) break;
+        if (lds_peek(&abort_flag)) break;
         if (++spins > a.spin_limit) { abort_flag = 1 | (s << 8); break; }
         __builtin_amdgcn_s_sleep(1);
       }

@@ -57,7 +57,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // s_memrealtime stamps (10 ns ticks) - 0 gather entered, 1 gather complete, 2 gate gradients done, 3 partial block in LDS,
 // 4 publish wave saw all four partial blocks, 5 publish + re-arm issued.  Timing aid only.
 #define SB_TRACE_STEPS 512
-__device__ unsigned long long sb_trace[SB_TRACE_STEPS * 8];
+#define SB_TRACE_ALL_STEPS 64                                       // ASR_SWEEP_DBG bit 256: EVERY workgroup of group 0 stamps "gather complete" and
+#define SB_TRACE_ALL_FIRST 64                                       // "publish issued" of steps [64, 128): [workgroup <= 64][step][2] behind the stage stamps
+__device__ unsigned long long sb_trace[SB_TRACE_STEPS * 8 + 64 * SB_TRACE_ALL_STEPS * 2];
 
 struct SbDir {
   const float* U; long ldu;
@@ -79,7 +81,7 @@ struct SbArgs {
   long xbytes;
   unsigned* err; float* err_flag;
   int spin_limit;
-  int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish
+  int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish, 16 no ds stores
   int delay;                    // s_sleep(2) periods before a gather's first poll
   int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
   float* ids;                   // [ngroups][nx][4]
@@ -90,7 +92,7 @@ struct SbArgs {
 
 // abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
 // gather waves, 3 publish wave waiting for the owner step, 4 publish wave waiting for its contraction partners
-__device__ __forceinline__ bool sb_wait(volatile int* c, int target, volatile int* abort_flag, int limit, int code) {
+__device__ __forceinline__ bool sb_wait(lds_flag_t c, int target, lds_flag_t abort_flag, int limit, int code) {
   for (int i = 0; *c < target; ++i) {
     if (*abort_flag) return false;
     if (i > limit) { *abort_flag = code; return false; }
@@ -210,28 +212,58 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     // mask: what the operand loads cost in front of the polls was measured at ~0.8 us of the 3.4 us step)
     constexpr int CW = CELL == CELL_RNN ? 4 : 8;
     struct Operands { f32x4 k0, k1; float dyv; };
+    // Buffer loads: (byte offset of the lane's (row, unit), fixed for the whole sweep, in a VGPR) + (byte offset of the step, wave-uniform,
+    // in an SGPR).  NO vector address arithmetic per step - with flat pointers the compiler computed each row's address in registers it
+    // had just named as a load destination and put `s_waitcnt vmcnt(0)` between the loads (round 4, from the ISA: the gather wave sat
+    // out the whole memory latency of its coefficient loads, 1.5 us from "partial block in LDS" to "next gather entered").  Rows beyond
+    // B point past the buffer: the hardware returns zeros.
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.coef), 0, (int)((long)B * T * H * CW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)((long)B * T * a.dy_ld * 4), 0x00020000);
+    unsigned cvo[NT], yvo[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) {
+      cvo[r] = live[r] ? (unsigned)((((long)brow[r] * T) * H + j) * CW * 4) : 0x80000000u;
+      yvo[r] = live[r] ? (unsigned)((((long)brow[r] * T) * a.dy_ld + d.y_col + j) * 4) : 0x80000000u;
+    }
+    const unsigned cstep = (unsigned)H * CW * 4, ystep = (unsigned)a.dy_ld * 4;   // bytes per time step
+    typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     auto fetch = [&](int p, Operands (&o)[NT]) {
-      const int step = T - 1 - p;
+      // straight-line: behind the last step the loads repeat the last step's (valid, unused) - a branch here would end in register
+      // copies at its join, and the compiler waits for the loads in front of those.  Only the components the gate gradients read are
+      // loaded: a destination register whose value is dead gets reused while the load is in flight, behind another wait
+      const int step = p < T ? T - 1 - p : 0;
       const int t = d.reverse ? T - 1 - step : step;
+      const unsigned cs = (unsigned)t * cstep, ys = (unsigned)t * ystep;
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        o[r].k0 = (f32x4){0.f, 0.f, 0.f, 0.f}; o[r].k1 = (f32x4){0.f, 0.f, 0.f, 0.f}; o[r].dyv = 0.f;
-        if (live[r] && p < T && !(a.dbg & 8)) {
-          const long bt = (long)brow[r] * T + t;
-          const float* cf = d.coef + (bt * H + j) * CW;
-          o[r].k0 = *reinterpret_cast<const f32x4*>(cf);
-          if (CW == 8) o[r].k1 = *reinterpret_cast<const f32x4*>(cf + 4);
-          o[r].dyv = a.dy[bt * a.dy_ld + d.y_col + j];
+        o[r].k1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (CELL == CELL_LSTM) {                          // k0 = {A, f, Co, m}, k1 = {Ci, Cf, Cg, -}
+          o[r].k0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)cvo[r], (int)cs, 0));
+          const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(crs, (int)(cvo[r] + 16u), (int)cs, 0);
+          o[r].k1.x = __uint_as_float(v.x); o[r].k1.y = __uint_as_float(v.y); o[r].k1.z = __uint_as_float(v.z);
+        } else if constexpr (CELL == CELL_GRU) {                    // k0 = {Cz, Cr, E, E r}, k1 = {z, m, -, -}
+          o[r].k0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, (int)cvo[r], (int)cs, 0));
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(crs, (int)(cvo[r] + 16u), (int)cs, 0);
+          o[r].k1.x = __uint_as_float(v.x); o[r].k1.y = __uint_as_float(v.y);
+        } else {                                                    // k0 = {1 - h^2, m, -, -}
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(crs, (int)cvo[r], (int)cs, 0);
+          o[r].k0 = (f32x4){__uint_as_float(v.x), __uint_as_float(v.y), 0.f, 0.f};
         }
+        o[r].dyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)yvo[r], (int)ys, 0));
       }
     };
-    Operands nxt[NT];
-    fetch(0, nxt);
+    Operands opA[NT], opB[NT];
+    fetch(0, opA);
+    int early = 0;                                                   // gathers of the current window whose first poll came too early
+    int dly = a.delay >= 0 ? a.delay : -a.delay;                     // s_sleep(2) periods in front of a gather's first poll (a.delay < 0: steered, starting there)
     // ds goes OUT OF PLACE.  The G workgroups of a square's row all read the same saved activations, one step ahead, and a row's
     // writer has no proof of where its row mates are: its gather returns blocks of column i, i.e. of the workgroups (i', i) - only
     // one of which is a row mate.  Writing ds over `saved` one step late (the first version of this kernel) therefore raced
     // with a slow row mate's fetch: seen as garbage gradients once other kernels ran beside the sweep (round 3, tests/tools/dbg_overlap.py).
-    for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
+    // The step body exists twice (steps 2q and 2q + 1) with the two operand register sets swapped: one loop body that fetches into
+    // the set it has just read ends in loop-carried register copies, and the compiler waits for the loads in front of those.
+    auto one_step = [&](const int p, const Operands (&cur)[NT], Operands (&nxt)[NT]) -> bool {   // false: the sweep is over (or aborted)
       const bool cell = p < T;
       const int step = T - 1 - p;
       const int t = cell ? (d.reverse ? T - 1 - step : step) : 0;
@@ -249,13 +281,17 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         const float* p3 = src + (u3 ? (long)(pt + 3 * LP) * blk : 0);
         f32x4 v0, v1, v2, v3;
         int spins = 0;
-        for (int w = 0; w < a.delay; ++w) __builtin_amdgcn_s_sleep(2);
+        // Poll as late as the data allows: every poll round of the chip is 4 MB of device-scope loads on the fabric the publishes travel
+        // on, and the hand-off gets slower with them (round 4, tests/tools/exp/bptt_knobs.py: 3.47 us per step polling from the start
+        // of the gather, 2.77 with the first poll timed to arrive just behind the data, 2.98 a quarter of a microsecond either side:
+        // a poll that comes too early costs a whole round trip, one that comes late costs its lateness).  The wave steers its own sleep.
+        for (int w = 0; w < dly; ++w) __builtin_amdgcn_s_sleep(2);
         if (a.probe) {
           for (;;) {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0) : "v"(p0) : "memory");
             const bool ok = !u0 || (__float_as_uint(v0.x) != SB_SENT && __float_as_uint(v0.w) != SB_SENT);
             if (__all(ok) || (a.dbg & 2)) break;
-            if (*(volatile int*)&abort_flag) break;
+            if (lds_peek(&abort_flag)) break;
             if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
             for (int w = 0; w < a.probe; ++w) __builtin_amdgcn_s_sleep(1);
           }
@@ -275,11 +311,21 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           };
           const bool ok = (!u0 || fresh(v0)) && (!u1 || fresh(v1)) && (!u2 || fresh(v2)) && (!u3 || fresh(v3));
           if (__all(ok) || (a.dbg & 2)) break;
-          if (*(volatile int*)&abort_flag) break;
+          if (lds_peek(&abort_flag)) break;
           if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
           __builtin_amdgcn_s_sleep(1);
         }
-        if (*(volatile int*)&abort_flag) break;
+        if (lds_peek(&abort_flag)) return false;
+        if (a.delay < 0) {
+          // steering, in windows of 8 steps: no early poll in the window -> start one period sooner; one -> hold (an isolated late sender
+          // is a glitch of the whole chip, not a reason to move); more -> later.  Deliberately slow: the workgroups are coupled, and a
+          // controller that answers every failed poll makes all of them drift late together after any disturbance
+          early += spins > 0 ? 1 : 0;
+          if ((p & 7) == 0) {
+            dly = early == 0 ? (dly > 0 ? dly - 1 : 0) : (early == 1 ? dly : (dly + (early > 3 ? 2 : 1) < 64 ? dly + (early > 3 ? 2 : 1) : 64));
+            early = 0;
+          }
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (u0) acc += v0;
         if (u1) acc += v1;
@@ -300,14 +346,20 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
       }
       if (tracing && lane == 0) sb_trace[p * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-      // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here)
+      if ((a.dbg & 256) && group == 0 && wv == 0 && lane == 0 && p >= SB_TRACE_ALL_FIRST && p < SB_TRACE_ALL_FIRST + SB_TRACE_ALL_STEPS && bx < 64)
+        sb_trace[SB_TRACE_STEPS * 8 + (bx * SB_TRACE_ALL_STEPS + p - SB_TRACE_ALL_FIRST) * 2] = __builtin_amdgcn_s_memrealtime();
+      // this step's operands were fetched a step ago (older than the gather's polls in the wave's in-order queue: already here); the
+      // next step's go out NOW, at the start of the local work: a wave's loads return in order, so whatever is still in flight when
+      // the next gather starts delays its first poll by the rest of a memory latency (issued behind the product, as until round 4,
+      // that was ~1 us of every step - sweep_trace.py)
       f32x4 k0[NT], k1[NT];
       float dyv[NT], addAv[NT];
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
-        k0[r] = nxt[r].k0; k1[r] = nxt[r].k1; dyv[r] = nxt[r].dyv; addAv[r] = 0.f;
+        k0[r] = cur[r].k0; k1[r] = cur[r].k1; dyv[r] = cur[r].dyv; addAv[r] = 0.f;
         if (p == 0 && live[r] && d.dh_last) addAv[r] = d.dh_last[(long)brow[r] * d.dh_last_ld + j];
       }
+      fetch(p + 1, nxt);
       float ds[NT][4];
 #pragma unroll
       for (int r = 0; r < NT; ++r) {
@@ -346,7 +398,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           dirv[r] = dir;
         }
       }
-      if (!cell) break;
+      if (!cell) return false;
       if (tracing && lane == 0) sb_trace[p * 8 + 2] = __builtin_amdgcn_s_memrealtime();
       // the wave's ds image in its own LDS rows, gate slots in the order the recurrent kernel's column blocks take them
       // (GRU: z, r, r (.) d(a_hh); the input-side slot 2 does not multiply U), then read back as MFMA A operands: lane (li, lq) =
@@ -372,11 +424,15 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
 #pragma unroll
       for (int t2 = 0; t2 < NT; ++t2) *reinterpret_cast<f32x4*>(&part[p & 1][wv][t2][lane * 4]) = acc[t2];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *(volatile int*)&g_done[wv] = p + 1;
+      if (lane == 0) lds_poke(&g_done[wv], p + 1);
       if (tracing && lane == 0) sb_trace[p * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-      // off the critical path from here: the operands of the next step.  (ds goes to memory from the publish waves: in this wave the
-      // stores would sit in front of the next gather's polls in the in-order memory counter - measured +0.76 us per step)
-      fetch(p + 1, nxt);
+      // (ds goes to memory from the publish waves: in this wave the stores would sit in front of the next gather's polls in the
+      // in-order memory counter - measured +0.76 us per step)
+      return true;
+    };
+    for (int p = 0; p <= T; p += 2) {                                // p = T: only the gradient wrt the initial state
+      if (!one_step(p, opA, opB)) break;
+      if (!one_step(p + 1, opB, opA)) break;
     }
     if (writer && CELL == CELL_LSTM && !abort_flag) {
 #pragma unroll
@@ -389,16 +445,26 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const long my_blk = ((long)gj_ * G + gi_) * blk + (long)nt_ * 256 + lane * 4;   // block (row j, sender i), this wave's tile
     const u32x4 sent = {SB_SENT, SB_SENT, SB_SENT, SB_SENT};
-    const bool writer = gj_ == 0 && !(a.dbg & 16);                    // column 0 of the square writes the layer's ds
+    // ds leaves the chip once per step from the G workgroups of row i together: the NS x NT (wave, piece) units of a workgroup are dealt
+    // round the G columns (unit m to column m % G).  Until round 4 column 0 wrote all of it - four more stores per lane and step than
+    // its row mates, 1.39 against 1.11 us of local work (tests/tools/sweep_trace_all.py), and every cycle of hand-offs that passes
+    // through a column-0 workgroup (all of them, within two steps) ran at ITS pace.
+    bool mine[NS];
+    bool writer = false;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      mine[k] = (k * NT + nt_) % G == gj_ && !(a.dbg & 16);
+      writer = writer || mine[k];
+    }
     f32x4 bsum[NS];                                                   // this lane's pieces summed over the steps: the bias gradient
 #pragma unroll
     for (int k = 0; k < NS; ++k) bsum[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < T; ++p) {
       bool ok = true;
       for (int i = 0;; ++i) {
-        const int v = *(volatile int*)&g_done[lane & 3];
+        const int v = lds_peek(&g_done[lane & 3]);
         if (__all(v >= p + 1)) break;
-        if (*(volatile int*)&abort_flag) { ok = false; break; }
+        if (lds_peek(&abort_flag)) { ok = false; break; }
         if (i > lds_limit) { abort_flag = 3 | (p << 8); ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -410,19 +476,8 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][2][nt_][lane * 4]);
       acc += *reinterpret_cast<const f32x4*>(&part[p & 1][3][nt_][lane * 4]);
       // retire the stores of the previous step (publish + sentinel, a whole exchange round old), then publish and re-arm.
-      // (A COUNTED wait would do - vmcnt(2), column 0: vmcnt(2 + NS), i.e. only the stores up to step p - 2 retired: the sentinel of
-      // step q must be visible before a reader polls that slot for its gather of step q + 4, which it reaches only after consuming
-      // this publisher's block of step q + 2, issued behind the wait of step q + 2.  It shortens this wave's part of the step from
-      // 0.6 to 0.24 us (tests/tools/sweep_trace.py) but not the step - the gather wave's own loop is as long: 3.27 -> 3.29 us
-      // alone, 785 vs 792 us per launch inside the training step.  ASR_SWEEP_DBG bit 64 keeps it for experiments.)
-      if (!(a.dbg & 64)) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
-      } else if (writer) {
-        if constexpr (NS == 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(3)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(2)" ::: "memory");
-      }
+      // (a counted wait - only the stores up to step p - 2 retired - shortens this wave's part of the step by 0.3 us but not the step)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");
       const long dst = ((long)group * SB_SLOTS + (p + 1) % SB_SLOTS) * slot_floats + my_blk;
       const long old = ((long)group * SB_SLOTS + (p + SB_SLOTS - 2) % SB_SLOTS) * slot_floats + my_blk;   // the block of step p - 3
       if (local) {                                                   // the group sits on one XCD: plain stores keep the lines in its L2
@@ -433,6 +488,8 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         if (p >= 3 && !(a.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b128(sent, rsrc, (int)(old * 4), 0, 16);
       }
       if (tracing && lane == 0) sb_trace[p * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+      if ((a.dbg & 256) && group == 0 && wv == 4 && lane == 0 && p >= SB_TRACE_ALL_FIRST && p < SB_TRACE_ALL_FIRST + SB_TRACE_ALL_STEPS && bx < 64)
+        sb_trace[SB_TRACE_STEPS * 8 + (bx * SB_TRACE_ALL_STEPS + p - SB_TRACE_ALL_FIRST) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
       if (writer) {
         // this step's ds, [B, T, NS * H] row-major: 16-byte pieces (row, gate, 4 units), consecutive lanes on consecutive pieces of a
         // (row, gate) run; the next step's `s_waitcnt vmcnt(0)` retires them a whole exchange round later
@@ -440,6 +497,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         const int step = T - 1 - p, t = d.reverse ? T - 1 - step : step;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
+          if (!mine[k]) continue;
           const int q = nt_ * 64 + lane + k * 64 * NT;                 // (16 * PPR = NS * 64 NT pieces: NS per lane, the same ones every step)
           const int row = q / PPR, rem = q % PPR, gate = rem / (4 * NT), u4 = rem % (4 * NT);
           const int sl = CELL == CELL_GRU ? (gate == 2 ? 3 : (gate == 3 ? 2 : gate)) : gate;   // image slot of this output slot
@@ -450,7 +508,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
       }
     }
-    if (writer && d.db && !*(volatile int*)&abort_flag) {
+    if (writer && d.db && !lds_peek(&abort_flag)) {
       // bias gradient.  A lane's NS pieces are the same (gate, unit quad) of different rows (64 NT k is a multiple of PPR), and so are
       // the lanes PPR apart: sum them in registers and across the wave first, then ONE atomic per bias element and wave (summing
       // every lane's pieces with atomics - 16 colliding adds per element - cost the GRU layers more than the pass over ds it replaces)
@@ -489,7 +547,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
 }
 
 extern "C" int asr_debug_sweep_trace(unsigned long long* out, int n) {
-  if (!out || n <= 0 || n > SB_TRACE_STEPS * 8) return ASR_ERR_ARG;
+  if (!out || n <= 0 || n > SB_TRACE_STEPS * 8 + 64 * SB_TRACE_ALL_STEPS * 2) return ASR_ERR_ARG;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sb_trace), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? ASR_OK : ASR_ERR_HIP;
 }
 
@@ -546,6 +604,7 @@ extern "C" int asr_rnn_sweep_bwd_supported(int rnn_type, int B, int T, int H, in
   if (ndir != 1 && ndir != 2) return 0;
   int nt, G;
   if (!sb_geometry(B, H, ndir, &nt, &G)) return 0;
+  if ((long)B * T * H * 32 >= 2147483647L) return 0;                 // coefficient packs / dy are read through 32-bit buffer offsets
   // all workgroups must be resident together: ask the device, keep a quarter of its capacity free (see rnn_sweep.hip)
   const long wgs = (long)ndir * asr_cdiv(B, 16) * G * G;
   const long cap = nt == 1 ? sb_capacity<1>(rnn_type) : sb_capacity<2>(rnn_type);
@@ -585,11 +644,12 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   a.prio = asr_sweep_prio();
   a.probe = getenv("ASR_SWEEP_BWD_PROBE") ? atoi(getenv("ASR_SWEEP_BWD_PROBE")) : 0;
-  // see rnn_sweep.hip.  Here the next step's operand loads already sit between a step's product and the next gather's first poll, so
-  // no extra delay pays inside the training step (las_small ms per step with 0 / 2 / 4 / 6 / 8 x 128 cycles: 11.87 / 11.92 / 11.99 /
-  // 12.03 / 12.10; alone, with nothing else on the device, 6-8 measured best)
-  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 0;
+  // sleep in front of a gather's first poll, in 128-cycle periods: negative = steered by each wave from its own poll counts, starting at
+  // |value| (default); >= 0 fixed.  (Until round 4 the next step's operand loads sat in front of the polls and were the delay.)
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : -16;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
+  ASR_CHECK(gs->dy_ld >= (long)s->ndir * H && (long)B * T * gs->dy_ld * 4 < 2147483647L, ASR_ERR_SHAPE,
+            "asr_rnn_sweep_bwd: dy is read through 32-bit buffer offsets (B T dy_ld floats beyond 2 GB, or dy_ld < ndir H)");
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->coef[d] && s->U[d] && (!lstm || gs->dc[d]), ASR_ERR_ARG, "asr_rnn_sweep_bwd: null buffer (dir %d): the BPTT sweep reads the coefficients the forward sweep wrote (s->coef)", d);
     ASR_CHECK(gs->ds[d] && (const float*)gs->ds[d] != s->coef[d], ASR_ERR_ARG, "asr_rnn_sweep_bwd: g->ds[%d] missing", d);
@@ -613,6 +673,8 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   // XCD-local placement only with one workgroup per compute unit of the XCD (32): two per CU measured slower than the chip-wide
   // placement (las_small square of 64: 4.4 against 3.4 us per step) - an explicit bound, not the occupancy answer, which moves with
   // every change of the kernel's register count
+  // (round 4, with the poll delay in place: the las_small square forced onto one XCD at two workgroups per CU = 3.02-3.07 us per step, the
+  // chip-wide placement 2.99-3.07: what the L2-local hand-off saves, the doubled work per compute unit costs)
   if (xcd_env && groups <= 8 && cap_all > 0 && G * G <= 32 && (long)G * G * 4 <= (cap_all / 8) * 3) {
     a.xcd = 1; a.nx = G * G; a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
     a.ids = ws + xslots;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
             u32x4 v;
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(pp) : "memory");
             if (__all(ww_fresh(v)) || (a.dbg & 2)) break;
-            if (*(volatile int*)&abort_flag) { ok2 = false; break; }
+            if (lds_peek(&abort_flag)) { ok2 = false; break; }
             if (spins > a.spin_limit) { abort_flag = 1 | (s << 8); ok2 = false; break; }
             __builtin_amdgcn_s_sleep(4);
           }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
 #pragma unroll
               for (int ks = 0; ks < KS; ++ks) ok = ok && ww_fresh(av[mt][ks]);
           if (__all(ok) || (a.dbg & 2)) { done = true; break; }
-          if (*(volatile int*)&abort_flag) break;
+          if (lds_peek(&abort_flag)) break;
           if (spins > a.spin_limit) { abort_flag = 2 | (s << 8); break; }
           __builtin_amdgcn_s_sleep(2);
         }

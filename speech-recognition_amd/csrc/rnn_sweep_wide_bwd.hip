@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   for (int p = 0; p <= T; ++p) {                                   // p = T: only the gradient wrt the initial state
     const bool cell = p < T;
     f32x4 dh = {0.f, 0.f, 0.f, 0.f};
-    volatile int* const abort_now = &abort_par[p & 1];
+    const lds_flag_t abort_now = lds_flag(&abort_par[p & 1]);
     if (p > 0) {
       // ---------------------------------------------------------------------------------------- gather (32 senders, 16 per thread)
       const uint32_t* src0 = a.xbuf + dir_words + (long)(p % WB_SLOTS) * WB_SLOT_WORDS + g_base;      // wave-uniform

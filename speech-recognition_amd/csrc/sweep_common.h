@@ -25,6 +25,17 @@
 #pragma once
 #include "common.h"
 
+// Progress words and abort flags live in LDS and are polled by the other waves of the workgroup.  They must be reached through
+// LDS-TYPED pointers: `volatile int*` is a generic pointer, address-space inference leaves volatile accesses alone, and the access
+// becomes flat_load / flat_store ... sc0 sc1 + s_waitcnt vmcnt(0) - the texture path's latency instead of a ds_read's, and an entry in
+// the wave's in-order memory counter in front of its polls (round 4: 186 such instructions in the decoder sweep, the BPTT sweep's
+// "partial block ready" mark waited for its own flat store).  Through these types the same source compiles to ds_read_b32 / ds_write_b32.
+typedef __attribute__((address_space(3))) int lds_int_t;
+typedef volatile lds_int_t* lds_flag_t;
+__device__ __forceinline__ lds_flag_t lds_flag(int* p) { return (lds_flag_t)p; }
+__device__ __forceinline__ int lds_peek(const int* p) { return *(const volatile lds_int_t*)p; }
+__device__ __forceinline__ void lds_poke(int* p, int v) { *(volatile lds_int_t*)p = v; }
+
 #define SWD_ARRIVED 4
 #define SWD_EXPECTED 5
 #define SWD_DEPARTED 6
