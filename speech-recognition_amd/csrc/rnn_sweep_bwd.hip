@@ -41,6 +41,7 @@
 // acknowledgements); LDS buffers are double-buffered by step parity and protected by causality through the exchange
 // (a gather of step p+2 cannot complete before this workgroup's own publish of step p+1).
 // Every spin is bounded; on time-out the error word (who gave up | step << 8) and the caller's sticky flag are raised.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sweep_common.h"
@@ -82,7 +83,8 @@ struct SbArgs {
   unsigned* err; float* err_flag;
   int spin_limit;
   int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish, 16 no ds stores
-  int delay;                    // s_sleep(2) periods before a gather's first poll
+  int delay;                    // s_sleep(2) periods before a gather's first poll (< 0: steered)
+  int win, lo, hi;              // steered delay: window (gathers), early starts allowed for 'sooner', early starts that mean 'later'
   int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
   float* ids;                   // [ngroups][nx][4]
   int prio;                     // s_setprio level of every wave
@@ -255,8 +257,12 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     };
     Operands opA[NT], opB[NT];
     fetch(0, opA);
-    int early = 0;                                                   // gathers of the current window whose first poll came too early
-    int dly = a.delay >= 0 ? a.delay : -a.delay;                     // s_sleep(2) periods in front of a gather's first poll (a.delay < 0: steered, starting there)
+    int early = 0, seen = 0, nfail = 0;                              // gathers of the current window that started too early / all of them; early ones of the sweep
+    int dly = a.delay >= 0 ? a.delay : -a.delay;
+    if (a.delay < 0) {                                               // what workgroup 0 had learned when this workspace's last sweep ended (word 28)
+      const unsigned learned = __hip_atomic_load(a.err + 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (learned >= 1u && learned <= 64u) dly = (int)learned;
+    }                     // s_sleep(2) periods in front of a gather's first poll (a.delay < 0: steered, starting there)
     // ds goes OUT OF PLACE.  The G workgroups of a square's row all read the same saved activations, one step ahead, and a row's
     // writer has no proof of where its row mates are: its gather returns blocks of column i, i.e. of the workgroups (i', i) - only
     // one of which is a row mate.  Writing ds over `saved` one step late (the first version of this kernel) therefore raced
@@ -317,15 +323,15 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         }
         if (lds_peek(&abort_flag)) return false;
         if (a.delay < 0) {
-          // steering, in windows of 8 steps: no early poll in the window -> start one period sooner; one -> hold (an isolated late sender
-          // is a glitch of the whole chip, not a reason to move); more -> later.  Deliberately slow: the workgroups are coupled, and a
-          // controller that answers every failed poll makes all of them drift late together after any disturbance
+          // steering, in windows of a.win gathers: at most a.lo of them started too early (a failed first poll) -> start one period
+          // sooner; a.hi or more -> one period later; between -> hold
           early += spins > 0 ? 1 : 0;
-          if ((p & 7) == 0) {
-            dly = early == 0 ? (dly > 0 ? dly - 1 : 0) : (early == 1 ? dly : (dly + (early > 3 ? 2 : 1) < 64 ? dly + (early > 3 ? 2 : 1) : 64));
-            early = 0;
+          if (++seen >= a.win) {
+            dly = early <= a.lo ? (dly > 0 ? dly - 1 : 0) : (early >= a.hi ? (dly < 64 ? dly + 1 : 64) : dly);
+            early = 0; seen = 0;
           }
         }
+        nfail += spins > 0 ? 1 : 0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (u0) acc += v0;
         if (u1) acc += v1;
@@ -433,6 +439,12 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     for (int p = 0; p <= T; p += 2) {                                // p = T: only the gradient wrt the initial state
       if (!one_step(p, opA, opB)) break;
       if (!one_step(p + 1, opB, opA)) break;
+    }
+    if (lane == 0) {                                                 // poll statistics (diagnosis words 25-27, accumulated until the host clears them)
+      atomicAdd(a.err + 25, (unsigned)nfail);
+      atomicAdd(a.err + 26, (unsigned)dly);
+      atomicAdd(a.err + 27, 1u);
+      if (a.delay < 0 && bx == 0 && by == 0 && bz == 0 && wv == 0 && !lds_peek(&abort_flag)) a.err[28] = (unsigned)(dly > 0 ? dly : 1);
     }
     if (writer && CELL == CELL_LSTM && !abort_flag) {
 #pragma unroll
@@ -647,6 +659,8 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   // sleep in front of a gather's first poll, in 128-cycle periods: negative = steered by each wave from its own poll counts, starting at
   // |value| (default); >= 0 fixed.  (Until round 4 the next step's operand loads sat in front of the polls and were the delay.)
   a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : -16;
+  a.win = 32; a.lo = 1; a.hi = 4;
+  if (const char* w = getenv("ASR_SWEEP_BWD_WIN")) sscanf(w, "%d,%d,%d", &a.win, &a.lo, &a.hi);
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   ASR_CHECK(gs->dy_ld >= (long)s->ndir * H && (long)B * T * gs->dy_ld * 4 < 2147483647L, ASR_ERR_SHAPE,
             "asr_rnn_sweep_bwd: dy is read through 32-bit buffer offsets (B T dy_ld floats beyond 2 GB, or dy_ld < ndir H)");
@@ -679,6 +693,9 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
     a.xcd = 1; a.nx = G * G; a.ny = asr_cdiv(B, 16); a.ngroups = (int)groups;
     a.ids = ws + xslots;
     grid = dim3((unsigned)(8 * a.nx), 1, 1);
+    // hand-offs that stay inside an XCD's L2 are short and their polls cheap: no sleep in front of them (DeepSpeech2 layer, H = 128:
+    // 1.95 us per step polling at once, 2.5 with the steered sleep, which waits for the 90th percentile of a short wait)
+    if (!getenv("ASR_SWEEP_BWD_DELAY")) a.delay = 0;
   }
   if (nt == 1) sb_launch<1>(s->rnn_type, grid, st, a);
   else sb_launch<2>(s->rnn_type, grid, st, a);

@@ -38,10 +38,20 @@ def run(iters=20):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def poll_stats():
+    w = pws[-32:].view(torch.int32)
+    nfail, dsum, waves = int(w[25]), int(w[26]), int(w[27])
+    w[25:28] = 0
+    return nfail / max(waves, 1) / (T - 1), dsum / max(waves, 1)
+
+
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["ASR_SWEEP_BWD_DELAY", "ASR_SWEEP_BWD_PROBE", "ASR_SWEEP_DBG"]
 grids = [[int(v) for v in a.split(",")] for a in sys.argv[2:]] or [[0, 4, 8, 12, 16, 24], [0, 1, 4], [0, 64]]
 for combo in itertools.product(*grids):
     for n, v in zip(names, combo):
         os.environ[n] = str(v)
+    poll_stats()
     us = run()
+    fr, dm = poll_stats()
+    print(f"early {fr:5.3f} final delay {dm:5.1f} ", end="")
     print(" ".join(f"{n.replace('ASR_SWEEP_', '')}={v}" for n, v in zip(names, combo)), f"{us:8.1f} us = {us / T:.3f} us/step", flush=True)
