@@ -83,13 +83,10 @@ struct SbArgs {
   unsigned* err; float* err_flag;
   int spin_limit;
   int dbg;                      // timing experiments only (ASR_SWEEP_DBG): 1 no re-arm, 2 no wait, 4 no publish, 16 no ds stores
-  int delay;                    // s_sleep(2) periods before a gather's first poll (< 0: steered)
-  int win, lo, hi;              // steered delay: window (gathers), early starts allowed for 'sooner', early starts that mean 'later'
+  int delay;                    // 10 ns ticks between entering a gather and its first poll
   int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
   float* ids;                   // [ngroups][nx][4]
   int prio;                     // s_setprio level of every wave
-  int probe;                    // 1: poll ONE piece per lane until it is fresh before the whole gather goes out (a quarter of the poll traffic:
-                                // for launches that share the memory system with throughput work released beside them)
 };
 
 // abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
@@ -257,12 +254,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
     };
     Operands opA[NT], opB[NT];
     fetch(0, opA);
-    int early = 0, seen = 0, nfail = 0;                              // gathers of the current window that started too early / all of them; early ones of the sweep
-    int dly = a.delay >= 0 ? a.delay : -a.delay;
-    if (a.delay < 0) {                                               // what workgroup 0 had learned when this workspace's last sweep ended (word 28)
-      const unsigned learned = __hip_atomic_load(a.err + 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (learned >= 1u && learned <= 64u) dly = (int)learned;
-    }                     // s_sleep(2) periods in front of a gather's first poll (a.delay < 0: steered, starting there)
+    int nfail = 0;                                                   // gathers of the sweep whose first poll came too early (diagnosis)
     // ds goes OUT OF PLACE.  The G workgroups of a square's row all read the same saved activations, one step ahead, and a row's
     // writer has no proof of where its row mates are: its gather returns blocks of column i, i.e. of the workgroups (i', i) - only
     // one of which is a row mate.  Writing ds over `saved` one step late (the first version of this kernel) therefore raced
@@ -279,6 +271,7 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       const bool tracing = (a.dbg & 128) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wv == 0 && p < SB_TRACE_STEPS;
       if (tracing && lane == 0) sb_trace[p * 8 + 0] = __builtin_amdgcn_s_memrealtime();
       if (p > 0) {
+        const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
         const float* src = xb + (long)(p % SB_SLOTS) * slot_floats + row_off + pos_off;
         const bool u0 = pt < G, u1 = pt + LP < G, u2 = pt + 2 * LP < G, u3 = pt + 3 * LP < G;
         const float* p0 = src + (u0 ? (long)pt * blk : 0);
@@ -290,17 +283,16 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         // Poll as late as the data allows: every poll round of the chip is 4 MB of device-scope loads on the fabric the publishes travel
         // on, and the hand-off gets slower with them (round 4, tests/tools/exp/bptt_knobs.py: 3.47 us per step polling from the start
         // of the gather, 2.77 with the first poll timed to arrive just behind the data, 2.98 a quarter of a microsecond either side:
-        // a poll that comes too early costs a whole round trip, one that comes late costs its lateness).  The wave steers its own sleep.
-        for (int w = 0; w < dly; ++w) __builtin_amdgcn_s_sleep(2);
-        if (a.probe) {
-          for (;;) {
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0) : "v"(p0) : "memory");
-            const bool ok = !u0 || (__float_as_uint(v0.x) != SB_SENT && __float_as_uint(v0.w) != SB_SENT);
-            if (__all(ok) || (a.dbg & 2)) break;
-            if (lds_peek(&abort_flag)) break;
-            if (++spins > a.spin_limit) { abort_flag = 1 | (p << 8); break; }
-            for (int w = 0; w < a.probe; ++w) __builtin_amdgcn_s_sleep(1);
-          }
+        // a poll that comes too early costs a whole round trip, one that comes late costs its lateness).  The sleep is a FIXED time
+        // (a.delay, 10 ns ticks of s_memrealtime - not cycles: the clock moves between and during the launches of a training step).
+        // Three self-tuning versions were built and measured and lost to it inside the training step, where it matters: steering by the
+        // rate of failed first polls (that rate has a floor - 5 % alone, 14 % in the step - whatever the delay, and every threshold drifts
+        // late there: 180 ticks, 10.1 ms per step against 9.58), the same with the learned delay carried from launch to launch, and
+        // timing the poll from the arrival the idle publish wave measures with one-piece probes (the workgroups wait for each other:
+        // whoever polls late makes the others' data late, and the measured arrival runs away - 5.5 us per step at a lead of 0.2 us).
+        if (a.delay > 0) {
+          const unsigned long long target = t_enter + (unsigned long long)a.delay;
+          while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(1);
         }
         for (;;) {
           asm volatile(
@@ -322,15 +314,6 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
           __builtin_amdgcn_s_sleep(1);
         }
         if (lds_peek(&abort_flag)) return false;
-        if (a.delay < 0) {
-          // steering, in windows of a.win gathers: at most a.lo of them started too early (a failed first poll) -> start one period
-          // sooner; a.hi or more -> one period later; between -> hold
-          early += spins > 0 ? 1 : 0;
-          if (++seen >= a.win) {
-            dly = early <= a.lo ? (dly > 0 ? dly - 1 : 0) : (early >= a.hi ? (dly < 64 ? dly + 1 : 64) : dly);
-            early = 0; seen = 0;
-          }
-        }
         nfail += spins > 0 ? 1 : 0;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (u0) acc += v0;
@@ -440,11 +423,9 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
       if (!one_step(p, opA, opB)) break;
       if (!one_step(p + 1, opB, opA)) break;
     }
-    if (lane == 0) {                                                 // poll statistics (diagnosis words 25-27, accumulated until the host clears them)
+    if (lane == 0) {                                                 // poll statistics (diagnosis words 25-27, sweep_common.h)
       atomicAdd(a.err + 25, (unsigned)nfail);
-      atomicAdd(a.err + 26, (unsigned)dly);
-      atomicAdd(a.err + 27, 1u);
-      if (a.delay < 0 && bx == 0 && by == 0 && bz == 0 && wv == 0 && !lds_peek(&abort_flag)) a.err[28] = (unsigned)(dly > 0 ? dly : 1);
+      atomicAdd(a.err + 26, 1u);
     }
     if (writer && CELL == CELL_LSTM && !abort_flag) {
 #pragma unroll
@@ -655,12 +636,10 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   a.prio = asr_sweep_prio();
-  a.probe = getenv("ASR_SWEEP_BWD_PROBE") ? atoi(getenv("ASR_SWEEP_BWD_PROBE")) : 0;
-  // sleep in front of a gather's first poll, in 128-cycle periods: negative = steered by each wave from its own poll counts, starting at
-  // |value| (default); >= 0 fixed.  (Until round 4 the next step's operand loads sat in front of the polls and were the delay.)
-  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : -16;
-  a.win = 32; a.lo = 1; a.hi = 4;
-  if (const char* w = getenv("ASR_SWEEP_BWD_WIN")) sscanf(w, "%d,%d,%d", &a.win, &a.lo, &a.hi);
+  // sleep in front of a gather's first poll, in 10 ns ticks (see the gather).  las_small layer, chip-wide square of 64 workgroups per group: 80 /
+  // 100 / 120 ticks = 9.71 / 9.58 / 9.68 ms per training step (9.76 before round 4, when the next step's operand loads sat in front of the
+  // polls and were the delay), 2.93 us per dependent step alone.
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 100;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   ASR_CHECK(gs->dy_ld >= (long)s->ndir * H && (long)B * T * gs->dy_ld * 4 < 2147483647L, ASR_ERR_SHAPE,
             "asr_rnn_sweep_bwd: dy is read through 32-bit buffer offsets (B T dy_ld floats beyond 2 GB, or dy_ld < ndir H)");

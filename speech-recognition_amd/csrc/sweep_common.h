@@ -22,6 +22,8 @@
 //                11 arrivals at that moment, 12 XCD-local mode (1) or write-through (0), 13 wave, 14 s_memrealtime (low word), 15 taken
 //   words 16-23  STICKY copy of the first such record since the host last cleared it (words 0-15 are re-armed by every launch, and
 //                the launch that failed is rarely the last one before anybody looks); word 24 launches that gave up since then
+//   words 25, 26 encoder BPTT sweep, poll statistics (accumulated until the host clears them): gathers whose first poll came too early,
+//                gather waves that reported
 #pragma once
 #include "common.h"
 
@@ -75,13 +77,16 @@ __device__ __forceinline__ bool swd_wait_all(unsigned* err, int spin_limit) {
   }
 }
 // one lane per workgroup, last thing in the kernel: the last one out re-arms the handshake for asr_sweep_gate
-__device__ __forceinline__ void swd_depart(unsigned* err) {
+// (returns true to the last workgroup out: everything the others did before their departure is visible to it)
+__device__ __forceinline__ bool swd_depart(unsigned* err) {
   const unsigned expected = __hip_atomic_load(err + SWD_EXPECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned n = __hip_atomic_fetch_add(err + SWD_DEPARTED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (expected != 0 && n + 1 == expected) {
     __hip_atomic_store(err + SWD_ARRIVED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(err + SWD_DEPARTED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
   }
+  return false;
 }
 // one lane of a workgroup that gave up: only the first caller of the launch leaves a record
 __device__ __forceinline__ void swd_record(unsigned* err, unsigned word, int local_mode) {

@@ -1,5 +1,6 @@
 """Encoder BPTT sweep (las_small layer) under its polling knobs, in one process:
-ASR_SWEEP_BWD_DELAY (s_sleep(2) periods before a gather's first poll) x ASR_SWEEP_BWD_PROBE x ASR_SWEEP_DBG bit 64 (counted store wait)."""
+ASR_SWEEP_BWD_DELAY (10 ns ticks between entering a gather and its first poll); prints the share of gathers whose first poll failed.
+  python tests/tools/exp/bptt_knobs.py [ENV_NAME[,ENV_NAME...] values,of,the,first values,of,the,second ...]"""
 import itertools
 import os
 import sys
@@ -40,18 +41,18 @@ def run(iters=20):
 
 def poll_stats():
     w = pws[-32:].view(torch.int32)
-    nfail, dsum, waves = int(w[25]), int(w[26]), int(w[27])
-    w[25:28] = 0
-    return nfail / max(waves, 1) / (T - 1), dsum / max(waves, 1)
+    nfail, waves = int(w[25]), int(w[26])
+    w[25:27] = 0
+    return nfail / max(waves, 1) / (T - 1)
 
 
-names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["ASR_SWEEP_BWD_DELAY", "ASR_SWEEP_BWD_PROBE", "ASR_SWEEP_DBG"]
-grids = [[int(v) for v in a.split(",")] for a in sys.argv[2:]] or [[0, 4, 8, 12, 16, 24], [0, 1, 4], [0, 64]]
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["ASR_SWEEP_BWD_DELAY"]
+grids = [[int(v) for v in a.split(",")] for a in sys.argv[2:]] or [[0, 60, 80, 90, 100, 110, 120, 140]]
 for combo in itertools.product(*grids):
     for n, v in zip(names, combo):
         os.environ[n] = str(v)
     poll_stats()
     us = run()
-    fr, dm = poll_stats()
-    print(f"early {fr:5.3f} final delay {dm:5.1f} ", end="")
+    fr = poll_stats()
+    print(f"early first polls {fr:5.3f} ", end="")
     print(" ".join(f"{n.replace('ASR_SWEEP_', '')}={v}" for n, v in zip(names, combo)), f"{us:8.1f} us = {us / T:.3f} us/step", flush=True)
