@@ -321,12 +321,18 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
         if (u2) acc += v2;
         if (u3) acc += v3;
         // the LP lanes of the position hold sums over disjoint senders
+        // (the partners sit in one quad: DPP quad_perm swaps, not ds_bpermute round trips through the LDS crossbar)
+        auto quad_xor = [](float v, int s2) {
+          const int i = __float_as_int(v);
+          return __int_as_float(s2 == 1 ? __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false)      // quad_perm [1,0,3,2]
+                                        : __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+        };
 #pragma unroll
         for (int s2 = 1; s2 < LP; s2 <<= 1) {
-          acc.x += __shfl_xor(acc.x, s2, 64);
-          acc.y += __shfl_xor(acc.y, s2, 64);
-          acc.z += __shfl_xor(acc.z, s2, 64);
-          acc.w += __shfl_xor(acc.w, s2, 64);
+          acc.x += quad_xor(acc.x, s2);
+          acc.y += quad_xor(acc.y, s2);
+          acc.z += quad_xor(acc.z, s2);
+          acc.w += quad_xor(acc.w, s2);
         }
 #pragma unroll
         for (int r = 0; r < NT; ++r) {
