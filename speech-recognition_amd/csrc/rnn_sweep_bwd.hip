@@ -87,6 +87,7 @@ struct SbArgs {
   int xcd, nx, ny, ngroups;     // XCD-local placement (see rnn_sweep.hip): 1-D grid, block b -> group b % 8, member b / 8
   float* ids;                   // [ngroups][nx][4]
   int prio;                     // s_setprio level of every wave
+  int rowxcd;                   // 1: block index -> (i = bx % G, j = bx / G)
 };
 
 // abort_flag doubles as the diagnosis: 0 = running, else (who gave up first) | (step << 8): 1 gather, 2 owner waiting for the other
@@ -128,7 +129,10 @@ __global__ __launch_bounds__(64 * (4 + NT)) void rnn_sweep_bwd_kernel(SbArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool gather_wave = wv < 4;
   const int li = lane & 15, lq = lane >> 4;
-  const int G = a.G, gi_ = bx / G, gj_ = bx % G;    // (i, j): ds of unit group i, partial dh of unit group j
+  // (i, j): ds of unit group i, partial dh of unit group j.  Consecutive blocks go to consecutive XCDs (round-robin dispatch), so with
+  // i = bx % G the G workgroups of a row - which all fetch the SAME coefficient packs, a gigabyte per las_small launch when each of them
+  // misses in an L2 of its own - sit on one XCD and share its L2 (a.rowxcd; 0 = the placement until round 4, column j on XCD j)
+  const int G = a.G, gi_ = a.rowxcd ? bx % G : bx / G, gj_ = a.rowxcd ? bx / G : bx % G;
   const int b0 = by * 16;
   const int B = a.B, T = a.T, H = a.H;
   const int group = bz * gy + by;
@@ -642,10 +646,11 @@ extern "C" int asr_rnn_sweep_bwd(const asr_rnn_seq* s, const asr_rnn_seq_grad* g
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   a.prio = asr_sweep_prio();
-  // sleep in front of a gather's first poll, in 10 ns ticks (see the gather).  las_small layer, chip-wide square of 64 workgroups per group: 80 /
-  // 100 / 120 ticks = 9.71 / 9.58 / 9.68 ms per training step (9.76 before round 4, when the next step's operand loads sat in front of the
-  // polls and were the delay), 2.93 us per dependent step alone.
-  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 100;
+  a.rowxcd = getenv("ASR_SWEEP_BWD_ROWXCD") ? atoi(getenv("ASR_SWEEP_BWD_ROWXCD")) : 1;
+  // sleep in front of a gather's first poll, in 10 ns ticks (see the gather).  las_small layer, chip-wide square of 64 workgroups per group, rows
+  // on XCDs: 70 / 80 / 90 / 100 / 110 ticks = 9.44 / 9.33 / 9.35 / 9.40 / 9.53 ms per training step (9.76 before round 4, when the next step's
+  // operand loads sat in front of the polls and were the delay), 2.66 us per dependent step alone at 90.
+  a.delay = getenv("ASR_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_SWEEP_BWD_DELAY")) : 85;
   ASR_CHECK(gs->dy, ASR_ERR_ARG, "asr_rnn_sweep_bwd: dy missing");
   ASR_CHECK(gs->dy_ld >= (long)s->ndir * H && (long)B * T * gs->dy_ld * 4 < 2147483647L, ASR_ERR_SHAPE,
             "asr_rnn_sweep_bwd: dy is read through 32-bit buffer offsets (B T dy_ld floats beyond 2 GB, or dy_ld < ndir H)");

@@ -32,7 +32,9 @@ torch.cuda.synchronize()
 n = 512 * 8 + 64 * 64 * 2
 buf = (C.c_ulonglong * n)()
 assert ops.lib().asr_debug_sweep_trace(buf, n) == 0
-t = np.array(buf[512 * 8:], dtype=np.float64).reshape(G, G, 64, 2) * 0.01     # [i][j][step][gather complete, publish issued] us
+t = np.array(buf[512 * 8:], dtype=np.float64).reshape(G, G, 64, 2) * 0.01     # [bx / G][bx % G][step][gather complete, publish issued] us
+if os.environ.get("ASR_SWEEP_BWD_ROWXCD", "1") != "0":                          # block -> (i = bx % G, j = bx / G): make it [i][j]
+    t = t.transpose(1, 0, 2, 3)
 gc, pub = t[..., 0], t[..., 1]
 local = pub - gc                                                              # gather complete -> publish issued, same step
 print(f"local work (gather complete -> publish issued): mean {local.mean():.3f} us, per workgroup min {local.mean(-1).min():.3f} max {local.mean(-1).max():.3f}")
