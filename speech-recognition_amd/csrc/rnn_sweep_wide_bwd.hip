@@ -69,6 +69,7 @@ struct WbArgs {
   uint32_t* xbuf; long xbytes;   // [ndir][6 slots][4 column blocks][32 senders][8 slices][64 rows][4 pieces][4 words]
   unsigned* err; float* err_flag;
   int spin_limit, dbg, prio;
+  int rowxcd;                    // block -> (row = x % 32, column = x / 32)
 };
 
 __device__ __forceinline__ bool wb_fresh(const u32x4& v) { return v.x != DS_SENT && v.y != DS_SENT && v.z != DS_SENT && v.w != DS_SENT; }
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(512) void rnn_sweepw_bwd_kernel(WbArgs a) {
   const WbDir& d = a.d[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int gi = blockIdx.x >> 2, gj = blockIdx.x & 3;            // grid row (unit group), grid column (output block)
+  // grid row (unit group), grid column (output block).  Consecutive blocks go to consecutive XCDs (round-robin dispatch): with a.rowxcd
+  // the 4 workgroups of a grid row - which gather the SAME 128 KB and fetch the same saved activations every step - share an XCD and its L2
+  const int gi = a.rowxcd ? (int)(blockIdx.x & 31) : (int)(blockIdx.x >> 2), gj = a.rowxcd ? (int)(blockIdx.x >> 5) : (int)(blockIdx.x & 3);
   const int B = a.B, T = a.T, H = a.H;
   if (tid == 0) { abort_par[0] = 0; abort_par[1] = 0; swd_arrive(a.err); }
   swd_setprio(a.prio);
@@ -377,6 +380,7 @@ extern "C" int asr_rnn_sweep_wide_bwd(const asr_rnn_seq* s, const asr_rnn_seq_gr
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.dbg = getenv("ASR_SWEEP_DBG") ? atoi(getenv("ASR_SWEEP_DBG")) : 0;
   a.prio = asr_sweep_prio();
+  a.rowxcd = getenv("ASR_SWEEP_WIDE_BWD_ROWXCD") ? atoi(getenv("ASR_SWEEP_WIDE_BWD_ROWXCD")) : 1;
   for (int d = 0; d < s->ndir; ++d) {
     ASR_CHECK(s->saved[d] && s->cseq[d] && s->U[d] && gs->dc[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: null buffer (dir %d)", d);
     ASR_CHECK(gs->ds[d] || gs->ds16[d] || gs->ds16T[d], ASR_ERR_ARG, "asr_rnn_sweep_wide_bwd: no destination for the gate-sum gradients: ds, ds16 or ds16T (dir %d)", d);
