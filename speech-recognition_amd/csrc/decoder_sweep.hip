@@ -48,7 +48,6 @@ struct DsArgs {
   int spin_limit, delay;
   int dbg;                                  // timing experiments only (ASR_DECODER_SWEEP_DBG): 2 = gathers do not wait
   int prio;                                 // s_setprio level of every wave
-  int rowxcd;                               // block -> (row, chunk) mapping of the attention role
 };
 
 // LONG: the general instance - chunks of more than DS_MAXTC frames (T' > 256: streamed-frame code) and / or a batch that runs in
@@ -79,9 +78,10 @@ __global__ __launch_bounds__(320) void decoder_sweep_fwd_kernel(DsArgs a) {
   const int Bs_ = LONG ? a.Bs : B, b0_ = LONG ? a.b0 : 0;
   const int Q = Hd >> 2, KBH = Hd >> 4, KBC = D >> 4;
   // attention role
-  // consecutive blocks go to consecutive XCDs (round-robin dispatch): with a.rowxcd the 8 chunk workgroups of a batch row - which exchange
-  // their partials with each other every step - share an XCD (block = chunk * 32 + row); 0 = block = row * 8 + chunk, one chunk per XCD
-  const int ab = a.rowxcd ? (w & 31) : (w >> 3), ac = a.rowxcd ? (w >> 5) : (w & 7);
+  // (block -> role placements measured in round 4, consecutive blocks going to consecutive XCDs: the 8 chunk workgroups of a batch row on one
+  // XCD 15.8 -> 16.4 us per decoder step, the 64 slice workgroups of a (layer, tile) on two XCDs 15.7 -> 16.6: both lose HERE and win in the
+  // backward sweep, which has them)
+  const int ab = w >> 3, ac = w & 7;
   const bool attn = ab < B;
   const int t_lo = ac * TC, nt = max(0, min(TC, T2 - t_lo));      // this chunk's frames
   const int atile = ab >> 4, arow = ab & 15;
@@ -642,8 +642,6 @@ extern "C" int asr_decoder_sweep_fwd(const asr_decoder_sweep* s, float* ws, floa
   a.err_flag = err_flag;
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.prio = asr_sweep_prio();
-  // (las_small geometry: 15.8 us per decoder step with one chunk per XCD, 16.4 with the rows on XCDs; the backward sweep gains from it)
-  a.rowxcd = getenv("ASR_DECODER_SWEEP_ROWXCD") ? atoi(getenv("ASR_DECODER_SWEEP_ROWXCD")) : 0;
   a.delay = getenv("ASR_DECODER_SWEEP_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_DELAY")) : 8;   // negative: timing experiment, gathers do not wait
   const size_t smem = ds_lds_bytes(s->Hd, s->D);
   static unsigned long long attr = 0;

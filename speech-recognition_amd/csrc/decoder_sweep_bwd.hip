@@ -46,6 +46,7 @@ struct DbArgs {
   unsigned* err; float* err_flag;
   int spin_limit, delay, dbg, prio;
   int rowxcd;                               // block -> (row, chunk) mapping of the attention role
+  int cellxcd;                              // block -> (gi, gj) mapping of the cell role
 };
 
 // up to 9 self-validating pieces per lane (layer 1: 4 partial-dH pieces, 4 dq pieces, 1 dc piece)
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(512) void decoder_sweep_bwd_kernel(DbArgs a) {
   const bool attn = ab < B;
   const int t_lo = ac * TC, nt = max(0, min(TC, T2 - t_lo));
   // cell role
-  const int layer = w >> 7, tile = (w >> 6) & 1, gi = (w & 63) >> 3, gj = w & 7;
+  // (a.cellxcd: row gi of a cell square on XCD gi - its 8 workgroups gather the same blocks and fetch the same saved activations, as
+  // in rnn_sweep_bwd.hip; 0: column gj on XCD gj)
+  const int layer = w >> 7, tile = (w >> 6) & 1, gi = a.cellxcd ? (w & 7) : ((w & 63) >> 3), gj = a.cellxcd ? ((w & 63) >> 3) : (w & 7);
   const bool cell = gi < G && gj < G && tile * 16 < B;
   const bool writer = gj == 0;
   const bool diag = gi == gj;
@@ -714,6 +717,7 @@ extern "C" int asr_decoder_sweep_bwd(const asr_decoder_sweep_grad* s, float* ws,
   a.spin_limit = asr_rnn_sweep_spin_limit();
   a.prio = asr_sweep_prio();
   // (las_small geometry: backward sweep 14.72 -> 14.36 us per decoder step with the rows on XCDs; the forward sweep loses, 15.8 -> 16.4, and keeps 0)
+  a.cellxcd = getenv("ASR_DECODER_SWEEP_CELLXCD") ? atoi(getenv("ASR_DECODER_SWEEP_CELLXCD")) : 1;   // (14.5 -> 14.15 us per decoder step)
   a.rowxcd = getenv("ASR_DECODER_SWEEP_ROWXCD") ? atoi(getenv("ASR_DECODER_SWEEP_ROWXCD")) : 1;
   a.delay = getenv("ASR_DECODER_SWEEP_BWD_DELAY") ? atoi(getenv("ASR_DECODER_SWEEP_BWD_DELAY")) : 4;
   const size_t smem = db_lds_bytes(s->Hd, s->D, nt);
