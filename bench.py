@@ -32,15 +32,15 @@ PEAK_HBM = 8.0e12          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # SURVEY.md 8d / BASELINE.md 4: algorithmic training flops per step = 3 x forward, key projection counted once
 WORKLOADS = {
     # traffic: memory-side bytes per step from the PMC passes of profiles/r04_las_small_pmc_hbm_traffic.txt (MiB per step there:
-    # FETCH_SIZE 6643.8, WRITE_SIZE 3862.2; 2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate,
-    # measured offline; dominant_traffic: the same for one launch of rnn_sweep_bwd_kernel (FETCH 3215.15 / 3, WRITE 930.05 / 3 MiB); about 60 % of it
-    # is the inter-workgroup exchange of the one-launch sweeps (write-through stores, L1-bypassing polls), which the counters
+    # FETCH_SIZE 3389.5, WRITE_SIZE 3862.6; 2 x FETCH_SIZE per the gfx950 correction for wide reads + WRITE_SIZE) - an upper estimate,
+    # measured offline; dominant_traffic: the same for one launch of rnn_sweep_bwd_kernel (FETCH 410.86 / 3, WRITE 931.36 / 3 MiB: until the rows of its workgroup squares sat on one XCD each, round 4, FETCH was 3215 - eight L2s fetching the same coefficient packs); most of the writes are
+    # the inter-workgroup exchange of the one-launch sweeps (write-through stores), which the counters
     # tally at the fabric although the Infinity Cache serves it
     # algorithmic_bytes: activations kept for backward written once + read once (2 x 0.9 GB), logits 131 MB x 5 touches,
     # Adam 28 B x 16 M parameters, features 51 MB, every weight matrix read twice (forward product, input gradient)
-    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=(2 * 6643.8 + 3862.2) * 2 ** 20, algorithmic_bytes=3.1e9,
+    "las_small": dict(model="las_small.yml", clip_seconds=10.0, batch=32, tokens=65, flops=363.3e9, traffic=(2 * 3389.5 + 3862.6) * 2 ** 20, algorithmic_bytes=3.1e9,
                       traffic_source="offline rocprofv3 PMC passes, profiles/r04_las_small_pmc_hbm_traffic.txt (not measured in this run)",
-                      dominant_traffic=(2 * 3215.15 + 930.05) / 3 * 2 ** 20,
+                      dominant_traffic=(2 * 410.86 + 931.36) / 3 * 2 ** 20,
                       metric="audio-seconds/sec training (las_small, 10s clips, bs32)",
                       text="las_small.yml + libri_config.yml, synthetic 10 s 16 kHz clips, batch 32 per GPU, 64 decoder steps, "
                            "SpecAugment+delta on GPU, dropout 0.15, teacher forcing on, fwd+bwd+Adam(lr 2e-4)"),
