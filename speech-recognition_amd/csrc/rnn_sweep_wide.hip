@@ -110,6 +110,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
   const long dir_words = (long)blockIdx.z * DS_SLOTS * a.slot_words;
 
+  int nretry = 0;                                          // whole gathers that found a stale piece (diagnosis word 25)
   for (int s = 0; s < T; ++s) {
     const int t = d.reverse ? T - 1 - s : s;
     // gate waves: operands that do not depend on the exchange
@@ -169,13 +170,19 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
         unsigned vo[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) vo[ks] = (unsigned)((((long)((w * KS + ks) * 4 + lq) * 64 + li) * 4) * 4);
+        // a k-step's pieces come from 4 of the 128 senders; the probe watched 16 of them, and one time in five a gather still finds
+        // somebody's piece stale (diagnosis word 25): only the k-steps that held one are read again, not the wave's whole 32 KB
+        bool need[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) need[ks] = true;
         for (int spins = 0; !done; ++spins) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=&v"(av[0][ks]) : "v"(vo[ks]), "s"(src) : "memory");
-            if (MT > 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:256 sc1" : "=&v"(av[1][ks]) : "v"(vo[ks]), "s"(src) : "memory");
-            if (MT > 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:512 sc1" : "=&v"(av[2][ks]) : "v"(vo[ks]), "s"(src) : "memory");
-            if (MT > 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:768 sc1" : "=&v"(av[3][ks]) : "v"(vo[ks]), "s"(src) : "memory");
+            if (!need[ks]) continue;                        // (wave-uniform)
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "+v"(av[0][ks]) : "v"(vo[ks]), "s"(src) : "memory");
+            if (MT > 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:256 sc1" : "+v"(av[1][ks]) : "v"(vo[ks]), "s"(src) : "memory");
+            if (MT > 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:512 sc1" : "+v"(av[2][ks]) : "v"(vo[ks]), "s"(src) : "memory");
+            if (MT > 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:768 sc1" : "+v"(av[3][ks]) : "v"(vo[ks]), "s"(src) : "memory");
           }
           // the loads above are in flight: tie every destination to the wait so that nothing reads them earlier
 #pragma unroll
@@ -193,11 +200,18 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
           }
           bool ok = true;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            if (mt < MT)
+          for (int ks = 0; ks < KS; ++ks) {
+            if (!need[ks]) continue;
+            bool okk = true;
 #pragma unroll
-              for (int ks = 0; ks < KS; ++ks) ok = ok && ww_fresh(av[mt][ks]);
-          if (__all(ok) || (a.dbg & 2)) { done = true; break; }
+            for (int mt = 0; mt < 4; ++mt)
+              if (mt < MT) okk = okk && ww_fresh(av[mt][ks]);
+            const bool fresh_k = __all(okk);
+            need[ks] = !fresh_k;
+            ok = ok && fresh_k;
+          }
+          if (ok || (a.dbg & 2)) { done = true; break; }
+          ++nretry;
           if (lds_peek(&abort_flag)) break;
           if (spins > a.spin_limit) { abort_flag = 2 | (s << 8); break; }
           __builtin_amdgcn_s_sleep(2);
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(384) void rnn_sweepw_fwd_kernel(WwArgs a) {
     }
   }
   __syncthreads();
+  if (!gate_wave && lane == 0) { atomicAdd(a.err + 25, (unsigned)nretry); atomicAdd(a.err + 26, 1u); }
   if (abort_flag && tid == 0) {
     __hip_atomic_store(a.err, (unsigned)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     swd_record(a.err, (unsigned)abort_flag, 0);

@@ -21,7 +21,9 @@ ws = ops.rnn_sweep_wide_ws(B, H, 2)
 t_w = time_fn(lambda: ops.rnn_sweep_wide_fwd(hip.seq, ws), 5)
 assert not ops.rnn_persist_error(ws) or os.environ.get("ASR_SWEEP_DBG"), "wide sweep timed out"
 t_s = time_fn(lambda: ops.rnn_seq_fwd(hip.seq), 3)
-print(f"B={B} T={T} H={H}: wide sweep {t_w:9.1f} us = {t_w / T:6.2f} us/step    step kernels {t_s:9.1f} us = {t_s / T:6.2f} us/step")
+w = ws[-32:].view(torch.int32)
+print(f"B={B} T={T} H={H}: wide sweep {t_w:9.1f} us = {t_w / T:6.2f} us/step    step kernels {t_s:9.1f} us = {t_s / T:6.2f} us/step"
+      f"    whole gathers repeated per wave and step {int(w[25]) / max(int(w[26]), 1) / (T - 1):.3f}")
 # the backward sweep (rnn_sweep_wide_bwd.hip) against the staged step kernels
 dy = torch.randn(B, T, 2 * H, generator=g).cuda() * 0.05
 ops.rnn_seq_fwd(hip.seq)
