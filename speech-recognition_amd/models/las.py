@@ -774,13 +774,15 @@ class LAS(ModelProto):
         if rate > 0:
             ops.dropout_flat(ws.dx0, self.seed, R.STREAM_CONV2_DROP, rate)
         dy2 = ws.dx0.view(B, T2, self.F2, 32)
-        ops.conv2d_bwd_filter(ws.c1, dy2, g["listener/conv2/kernel"], 2)
-        ops.colsum(dy2.view(-1, 32), g["listener/conv2/bias"])
+        # the chain the update waits for is dropout -> conv2's input gradient -> dropout -> conv1's filter gradient; conv2's filter /
+        # bias gradients and conv1's bias gradient run beside it (round 4, from the step's timeline: the seven kernels were one serial
+        # run of 400 us at the end of the step while the other stream sat idle)
+        ov.defer(lambda: (ops.conv2d_bwd_filter(ws.c1, dy2, g["listener/conv2/kernel"], 2), ops.colsum(dy2.view(-1, 32), g["listener/conv2/bias"])))
         ops.conv2d_bwd_data(dy2, p["listener/conv2/kernel"], ws.dc1, 2)
         if rate > 0:
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
+        ov.defer(lambda: ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"]))
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
-        ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"])
         ov.join_all()
 
     # ------------------------------------------------------------------------------------------ reference API
