@@ -10,6 +10,7 @@ the network output collapses to the Dense bias (could not be co
 TF).  "intended" (default) uses the product of the time strides; "reference_compat" reproduces the
 all-False mask.
 """
+import os
 import random
 from collections import OrderedDict
 from typing import List, Optional
@@ -285,10 +286,19 @@ class DeepSpeech2(ModelProto):
         self._ov.flush(join=False)         # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
         dy = ws.dx0.view(ws.conv[-1].shape)
+        beside = os.environ.get("ASR_DS2_CONV_BESIDE", "1") != "0" and self._ov.on
         for k in range(len(ws.conv) - 1, -1, -1):
             x = audio if k == 0 else ws.conv[k - 1]
-            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
-            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
+
+            def filter_and_bias(x=x, dy=dy, k=k):
+                ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
+                ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
+            # the chain the update waits for is the input gradients down to the bottom layer's filter gradient; the upper layers'
+            # filter / bias gradients run beside it
+            if k > 0 and beside:
+                self._ov.defer(filter_and_bias)
+            else:
+                filter_and_bias()
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]
