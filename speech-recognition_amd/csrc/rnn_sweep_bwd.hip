@@ -30,13 +30,13 @@
 // All stores to one word come from one wave in program order.  (Do NOT let the reader re-arm: two agents storing to the same
 // word race even when one store is issued only after the other was seen retired.)
 //
-// Wave roles (512 threads).  gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave with
+// Wave roles (64 x (4 + NT) threads).  gfx950 counts a wave's loads and stores in ONE in-order counter (vmcnt), so a wave with
 // write-through stores in flight cannot consume a later load before their acknowledgements are back:
-//   waves 0-3  GATHER + OWNER: poll the G blocks, add them up (registers, then LDS), gate-gradient math of the 16 x KU (row, unit)
-//              pairs from the forward sweep's coefficient packs, ds to LDS;
-//   waves 4-7  PUBLISH: multiply ds with the resident block of U^T (contraction split over the waves, summed through LDS),
-//              publish the [16 x KU] block, re-arm the block of three steps ago, write ds out of place (column j = 0 of the square) and
-//              sum the bias gradients.  They never load from global memory.
+//   waves 0-3  GATHER + OWNER: sleep until the blocks are due, poll the G blocks, add them up, fetch the NEXT step's coefficient packs
+//              (buffer loads, at the start of the local work), gate-gradient math of the 16 x KU (row, unit) pairs, ds to LDS, product;
+//   waves 4..  PUBLISH (one per 16-unit output tile): add the gather waves' four partial blocks (the contraction is split over them),
+//              publish the [16 x KU] block, re-arm the block of three steps ago, write ds out of place (each column of the square its
+//              share of a row's pieces) and sum the bias gradients.  They never load from global memory.
 // The roles hand over through LDS counters (a workgroup barrier would make the gather waves wait for store
 // acknowledgements); LDS buffers are double-buffered by step parity and protected by causality through the exchange
 // (a gather of step p+2 cannot complete before this workgroup's own publish of step p+1).

@@ -302,7 +302,7 @@ class DeepSpeech2(ModelProto):
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]
-        self._ov.join_all()
+        self._ov.flush()                   # (flush, not join_all: in "beside" mode defer() only queues, and nothing is left to run beside)
         self._side.join()
 
     # ------------------------------------------------------------------------------------------ reference API

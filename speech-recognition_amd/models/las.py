@@ -783,7 +783,7 @@ class LAS(ModelProto):
             ops.dropout_flat(ws.dc1, self.seed, R.STREAM_CONV1_DROP, rate)
         ov.defer(lambda: ops.colsum(ws.dc1.view(-1, 32), g["listener/conv1/bias"]))
         ops.conv2d_bwd_filter(audio, ws.dc1, g["listener/conv1/kernel"], 2)
-        ov.join_all()
+        ov.flush()                         # (flush, not join_all: in "beside" mode defer() only queues, and nothing is left to run beside)
 
     # ------------------------------------------------------------------------------------------ reference API
     def get_loss_fn(self):
