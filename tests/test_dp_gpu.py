@@ -230,5 +230,9 @@ def test_data_parallel_code_path_on_one_gpu_with_a_single_rank_rccl_group():
                 assert diff <= max(1e-5, 10 * noise), (name, diff, noise)
                 assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
             else:
-                assert diff <= 2e-2, (name, diff)                 # lr 1e-2 x 4 steps of sign-like Adam updates, gradients rounded to bf16 on the wire
+                # (lr 1e-2 x 4 steps of sign-like Adam updates, gradients rounded to bf16 on the wire.)  Under mixed precision two runs of the
+                # SAME path occasionally differ by as much as the full 4 x lr on single entries - an f32 difference from the atomically
+                # accumulated sums that straddles a bf16 rounding boundary moves a product by 2^-8, and Adam turns the sign of a near-zero
+                # gradient into a whole update (seen: 2.9e-8, 4e-3, 3.6e-2) - so the bound follows the noise measured in this very process
+                assert diff <= max(2e-2, 1.5 * noise), (name, diff, noise)
                 assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(single["losses"], dp["losses"]))
