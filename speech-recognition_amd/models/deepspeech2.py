@@ -286,19 +286,13 @@ class DeepSpeech2(ModelProto):
         self._ov.flush(join=False)         # no sweep left: the bottom layer's weight gradients run beside the convolutions' backward pass
         # convolutions (deepspeech2.py:57-59), no dropout / activation in between
         dy = ws.dx0.view(ws.conv[-1].shape)
-        beside = os.environ.get("ASR_DS2_CONV_BESIDE", "1") != "0" and self._ov.on
+        # (round 4 tried the upper layers' filter / bias gradients on the side stream beside this chain, as in las.py: 12.23 -> 12.14 ms per
+        # step, but at the full geometry (B = 16, 15 s) conv1's input gradient - the row-staged kernel - came out as garbage with a filter-
+        # gradient kernel running beside it; the small geometries pass.  Not understood yet, so the chain stays on one stream here.)
         for k in range(len(ws.conv) - 1, -1, -1):
             x = audio if k == 0 else ws.conv[k - 1]
-
-            def filter_and_bias(x=x, dy=dy, k=k):
-                ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
-                ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
-            # the chain the update waits for is the input gradients down to the bottom layer's filter gradient; the upper layers'
-            # filter / bias gradients run beside it
-            if k > 0 and beside:
-                self._ov.defer(filter_and_bias)
-            else:
-                filter_and_bias()
+            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
+            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]
