@@ -479,9 +479,15 @@ static HaloPlan halo_plan(const asr_conv_desc* d, int which) {
   auto rounds = [&](int rg) { return rg < 1 ? 1L << 40 : (((groups + rg - 1) / rg + d->sh * (which ? 1 : 0)) * p.NT + 255) / 256; };
   const bool can2 = d->kw == 11 && rg2 >= 1 && (rg2 * p.GW * 8 + 255) / 256 <= 14;
   const bool can1 = (size_t)rg1 * p.GW * 192 + (size_t)p.S * 6144 <= 158 * 1024 && (rg1 * p.GW * 8 + 255) / 256 <= 14 && (p.S * 384 + 255) / 256 <= 18;
+  // Version 2 is NOT taken by default any more (end of round 4): with kernels of another stream running beside it - the arrangement of
+  // tests/tools/exp/ds2_beside_dbg.py, conv2's input gradient beside two filter-gradient kernels - single workgroups of it produced garbage
+  // (5 600-36 400 of 13 M elements around 1e26, in 3 of 6 trials; version 1 and the general kernel: 0 of 12 and 0 of 9 in the same arrangement;
+  // alone it has never differed from the float64 reference).  Its hand-counted waits and LDS hand-overs look right on paper and the cause is not
+  // found, so a training step does not depend on it: ASR_CONV_HALO_V=2 asks for it explicitly, and the parity tests (asr_conv2d_halo_force)
+  // keep exercising it.  Cost: deepspeech conv2 forward 488 -> ~600 us, input gradient 589 -> ~650 us.
   if (ver_env == 1) p.ver = can1 ? 1 : 0;
-  else if (ver_env == 2) p.ver = can2 ? 2 : 0;
-  else p.ver = (can2 && (!can1 || 0.85 * rounds(rg2) <= 1.0 * rounds(rg1))) ? 2 : (can1 ? 1 : 0);
+  else if (ver_env == 2 || (ver_env == 0 && force)) p.ver = (can2 && (ver_env == 2 || !can1 || 0.85 * rounds(rg2) <= 1.0 * rounds(rg1))) ? 2 : (can1 ? 1 : 0);
+  else p.ver = can1 ? 1 : 0;
   if (!p.ver) return p;
   p.RG = p.ver == 2 ? rg2 : rg1;
   p.rows = p.RG * p.GW;

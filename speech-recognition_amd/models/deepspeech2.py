@@ -289,10 +289,22 @@ class DeepSpeech2(ModelProto):
         # (round 4 tried the upper layers' filter / bias gradients on the side stream beside this chain, as in las.py: 12.23 -> 12.14 ms per
         # step, but at the full geometry (B = 16, 15 s) conv1's input gradient - the row-staged kernel - came out as garbage with a filter-
         # gradient kernel running beside it; the small geometries pass.  Not understood yet, so the chain stays on one stream here.)
+        beside_mask = int(os.environ.get("ASR_DS2_CONV_BESIDE", "0"))      # (experiment: bit k = layer k's filter / bias gradients on the side stream)
         for k in range(len(ws.conv) - 1, -1, -1):
             x = audio if k == 0 else ws.conv[k - 1]
-            ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
-            ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
+
+            def filter_and_bias(x=x, dy=dy, k=k):
+                ops.conv2d_bwd_filter(x, dy, g[f"convolution/conv_layers/{k}/kernel"], self.strides[k])
+                ops.colsum(dy.view(-1, dy.shape[-1]), g[f"convolution/conv_layers/{k}/bias"])
+            sync_pt = int(os.environ.get("ASR_DS2_CONV_SYNC", "0"))
+            if sync_pt == 10 + k:
+                torch.cuda.synchronize()
+            if (beside_mask >> k) & 1 and self._ov.on:
+                self._ov.defer(filter_and_bias)
+            else:
+                filter_and_bias()
+            if sync_pt == 20 + k:
+                torch.cuda.synchronize()
             if k > 0:
                 ops.conv2d_bwd_data(dy, p[f"convolution/conv_layers/{k}/kernel"], ws.dconv[k - 1], self.strides[k])
                 dy = ws.dconv[k - 1]

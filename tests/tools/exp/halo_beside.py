@@ -32,13 +32,16 @@ ops.conv2d_bwd_data(dy1, w1, dx_ref, tuple(st[1]))
 torch.cuda.synchronize()
 print("row-staged route taken:", ops._conv_halo_ws(ops.conv_desc(dx_ref.shape, w1.shape, tuple(st[1])), 1) is not None)
 side = torch.cuda.Stream()
-gw2 = torch.zeros_like(w2)
+gw2, gw1 = torch.zeros_like(w2), torch.zeros_like(w1)
 worst = 0.0
-for it in range(6):
+for it in range(8):
     dx = torch.full_like(x1, float("nan"))
     torch.cuda.synchronize()
     with torch.cuda.stream(side):
-        ops.conv2d_bwd_filter(x2, dy2, gw2, tuple(st[2]))
+        if it < 4:
+            ops.conv2d_bwd_filter(x2, dy2, gw2, tuple(st[2]))       # conv3's filter gradient beside it
+        else:
+            ops.conv2d_bwd_filter(x1, dy1, gw1, tuple(st[1]))       # conv2's own filter gradient (same dy) beside it: the pair of the failing step
     ops.conv2d_bwd_data(dy1, w1, dx, tuple(st[1]))
     torch.cuda.synchronize()
     d = float((dx - dx_ref).abs().max())
